@@ -1,0 +1,62 @@
+"""Shared definitions of the parity cases (TEST INFRASTRUCTURE).
+
+Each case is a dict of numpy inputs built only from oracle/synth.py, so the
+golden generator (reference side), the oracle tests and the GPU parity tests all
+regenerate bit-identical inputs without storing them.
+"""
+import functools
+
+import numpy as np
+
+from . import synth
+
+F32 = np.float32
+
+
+@functools.lru_cache(maxsize=None)
+def build_case(name):
+    """Cached: callers must treat the returned arrays as read-only."""
+    if name == "tiny":          # B=2, odd N, 32^2 image, 16^3 voxels (coarsest map is 1^3)
+        return _case(seed=101, batch=2, n=129, img_res=32, vox_res=16)
+    if name == "small":         # B=3, 64^2 image, 32^3 voxels
+        return _case(seed=202, batch=3, n=200, img_res=64, vox_res=32)
+    if name == "real":          # the metric's map sizes, few points
+        return _case(seed=333, batch=1, n=64, img_res=224, vox_res=128)
+    if name == "edge":
+        return _edge_case()
+    raise KeyError(name)
+
+
+def _case(seed, batch, n, img_res, vox_res):
+    return {
+        "query": synth.make_query(seed, batch, n),
+        "img_maps": synth.make_img_maps(seed, batch, img_res),
+        "vox_maps": synth.make_vox_maps(seed, batch, vox_res),
+        "trans_mat": synth.make_trans_mat(seed, batch),
+        "weights": synth.make_mlp_weights(seed),
+    }
+
+
+def _edge_case():
+    """Points on the +-1 faces, projections clamped at 0 and at 136 (dropped tap),
+    Z+1e-8 <= 0 (sign flip / inf -> clamp), displaced coordinates outside [-1,1]."""
+    c = _case(seed=404, batch=1, n=64, img_res=32, vox_res=16)
+    q = c["query"].copy()
+    corners = np.array([[s0, s1, s2] for s0 in (-0.5, 0.5) for s1 in (-0.5, 0.5)
+                        for s2 in (-0.5, 0.5)], dtype=F32)
+    q[0, :8] = corners                      # all eight cube corners (p = +-1 after *2)
+    q[0, 8] = (0.5, 0.0, 0.0)
+    q[0, 9] = (0.0, -0.5, 0.0)
+    q[0, 10] = (0.0, 0.0, 0.5)
+    q[0, 11] = (0.0, 0.0, 0.0)              # centre -> voxel coordinate exactly (W-1)/2
+    q[0, 12] = (0.4639, -0.4639, 0.4639)    # displaced stencil points leave [-1,1]
+    c["query"] = q
+    # camera: u = 68 + 136*px', v = 68 - 136*py', Z = 1 + 2*pz'  (px' = permuted/scaled coords)
+    # -> plenty of clamping at 0 and 136, and Z <= 0 for pz' <= -0.5
+    T = np.array([[[136.0, 0.0, 0.0], [0.0, -136.0, 0.0], [0.0, 0.0, 2.0], [68.0, 68.0, 1.0]]],
+                 dtype=F32)
+    c["trans_mat"] = T
+    return c
+
+
+CASE_NAMES = ("tiny", "small", "real", "edge")
