@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""bench.py -- SDF query-points/sec of the LIST hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic input that is
+already resident in HBM in the REFERENCE's layout (NCHW / NCDHW fp32 feature maps, raw queries):
+  layout hand-off (resize-to-137^2 + NHWC, NCDHW->NDHWC) -> weight repack -> gathers -> MLP -> sdf,
+plus, for N > 1 ranks, the RCCL all-gather of the SDF shards (the loss-reduction exchange).
+Each rank owns B images (weak scaling: the batch x query axis is sharded, no other collective).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W_FLOP_PER_PT = 2 * (3610 * 512 + 512 * 256 + 256 * 256 + 256)      # 4 090 368
+W_BYTE_PER_PT = (7 * 8 * 369 + 4 * 1024) * 4 + 16                     # 99 056 fp32 maps
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
+PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA
+
+WORKLOADS = {
+    # name: (B per GPU, N, img_res, vox_res, map_size, clamp_hi)
+    "list_im2sdf_b8_n20k_224": (8, 20000, 224, 128, 137, 136.0),            # BASELINE configs[1]
+    "list_im2sdf_b8_n50k_512": (8, 50000, 512, 128, 274, 273.0),            # BASELINE configs[4]
+}
+
+
+class HipEvents:
+    """hipEvent_t through ctypes (torch.cuda.Event exposes no stable raw handle before record)."""
+
+    def __init__(self):
+        self.rt = ctypes.CDLL("libamdhip64.so")
+        self.rt.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self.rt.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self.rt.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p,
+                                                ctypes.c_void_p]
+        self.rt.hipEventDestroy.argtypes = [ctypes.c_void_p]
+
+    def create(self):
+        e = ctypes.c_void_p()
+        rc = self.rt.hipEventCreate(ctypes.byref(e))
+        assert rc == 0, rc
+        return e
+
+    def record(self, e):
+        rc = self.rt.hipEventRecord(e, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, rc
+
+    def elapsed_ms(self, a, b):
+        ms = ctypes.c_float()
+        rc = self.rt.hipEventElapsedTime(ctypes.byref(ms), a, b)
+        assert rc == 0, rc
+        return ms.value
+
+
+def make_inputs(workload, rank, device):
+    """Synthetic inputs of SURVEY 8d, generated on the device (torch RNG, seed 333 + rank):
+    image maps N(0,1), voxel level 0 U(0,1), levels 1-5 N(0,1), queries U(-0.5,0.5)^3, synthetic camera."""
+    from oracle import synth            # shapes + exact weight/camera generators only
+    B, N, img_res, vox_res, map_size, clamp_hi = WORKLOADS[workload]
+    g = torch.Generator(device=device)
+    g.manual_seed(333 + rank)
+    img_maps = [torch.randn(s, generator=g, device=device) for s in synth.img_map_shapes(B, img_res)]
+    vshapes = synth.vox_map_shapes(B, vox_res)
+    vox_maps = [torch.rand(vshapes[0], generator=g, device=device)]
+    vox_maps += [torch.randn(s, generator=g, device=device) for s in vshapes[1:]]
+    query = torch.rand((B, N, 3), generator=g, device=device) - 0.5
+    trans = torch.from_numpy(synth.make_trans_mat(333 + rank, B)).to(device)
+    if map_size != 137:                    # keep projections inside the larger map
+        trans = trans * (map_size - 1) / 136.0
+        trans[:, :, 2] = trans[:, :, 2] * 136.0 / (map_size - 1)
+    weights = {k: torch.from_numpy(v).to(device) for k, v in synth.make_mlp_weights(333).items()}
+    return dict(B=B, N=N, img_maps=img_maps, vox_maps=vox_maps, query=query, trans_mat=trans,
+                weights=weights, map_size=map_size, clamp_hi=clamp_hi)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="list_im2sdf_b8_n20k_224", choices=sorted(WORKLOADS))
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-images", type=int, default=2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        args.gpus = world
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import __graft_entry__ as ge
+    ge.build()
+    from list_amd import hip
+    from list_amd.parallel import gather_sdf_shards
+
+    inp = make_inputs(args.workload, rank, device)
+    B, N = inp["B"], inp["N"]
+    ev = HipEvents()
+    n_ev = hip.N_STAGES
+    # per-step events: [prep_begin, prep_img_end, prep_vox_end(=weights begin), weights_end] + stages
+    step_events = []
+    for _ in range(args.steps):
+        pre = [ev.create() for _ in range(4)]
+        arr = (ctypes.c_void_p * n_ev)(*[ev.create() for _ in range(n_ev)])
+        step_events.append((pre, arr))
+    gathered = torch.empty((world * B, N), dtype=torch.float32, device=device) if world > 1 else None
+    sdf = torch.empty((B, N), dtype=torch.float32, device=device)
+
+    def step(events=None):
+        pre, arr = events if events else (None, None)
+        if pre: ev.record(pre[0])
+        img = hip.prep_img_maps(inp["img_maps"], inp["map_size"])
+        if pre: ev.record(pre[1])
+        vox = hip.prep_vox_maps(inp["vox_maps"])
+        if pre: ev.record(pre[2])
+        packed = hip.prep_mlp_weights(inp["weights"], vox.channels, img.channels)
+        if pre: ev.record(pre[3])
+        hip.sdf_query(inp["query"], inp["trans_mat"], img, vox, packed, precision=args.precision,
+                      out=sdf, stage_events=arr)
+        if world > 1:
+            gather_sdf_shards(sdf, out=gathered)
+        return sdf
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(step_events[i])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel-stage durations from the events recorded inside the timed region
+    names = ["prep_img_resize_nhwc", "prep_vox_ndhwc", "prep_weights"] + list(hip.STAGE_NAMES)
+    acc = np.zeros(len(names))
+    for pre, arr in step_events:
+        acc[0] += ev.elapsed_ms(pre[0], pre[1])
+        acc[1] += ev.elapsed_ms(pre[1], pre[2])
+        acc[2] += ev.elapsed_ms(pre[2], pre[3])
+        for s in range(n_ev - 1):
+            acc[3 + s] += ev.elapsed_ms(ctypes.c_void_p(arr[s]), ctypes.c_void_p(arr[s + 1]))
+    stage_ms = dict(zip(names, (acc / args.steps).tolist()))
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    P = B * N
+    value = world * P * args.steps / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- roofline of the dominant kernel (stage) ------------------------------------------------
+    dom = max(hip.STAGE_NAMES, key=lambda k: stage_ms[k])
+    terms = 3 if args.precision == "bf16x3" else 1
+    vox_c = [1, 16, 32, 64, 128, 128]
+    if dom in ("gather_vox", "gather_img_tail"):
+        per_pt = (7 * 8 * sum(vox_c[1:]) * 4) if dom == "gather_vox" else (4 * 1024 * 4 + 7 * 8 * 4 + 16)
+        achieved = P * per_pt / (stage_ms[dom] * 1e-3) / 1e9
+        roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS,
+                "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": None,
+                "algorithmic_bytes_per_point": per_pt}
+    else:
+        flop_pt = {"fc_0": 2 * 3610 * 512, "fc_1": 2 * 512 * 256, "fc_2_out": 2 * (256 * 256 + 256)}[dom]
+        achieved = P * flop_pt / (stage_ms[dom] * 1e-3) / 1e12
+        roof = {"kernel": "k_gemm_nt (" + dom + ")", "bound": "mfma", "achieved": achieved,
+                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+                "traffic": None, "algorithmic_flop_per_point": flop_pt,
+                "mfma_products_per_mac": terms}
+    gather_ms = stage_ms["gather_vox"] + stage_ms["gather_img_tail"]
+    mlp_ms = stage_ms["fc_0"] + stage_ms["fc_1"] + stage_ms["fc_2_out"]
+    path = {
+        "gather_GBps_algorithmic": P * W_BYTE_PER_PT / (gather_ms * 1e-3) / 1e9,
+        "gather_frac_of_hbm_peak": P * W_BYTE_PER_PT / (gather_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+        "mlp_TFLOPs_algorithmic": P * W_FLOP_PER_PT / (mlp_ms * 1e-3) / 1e12,
+        "mlp_frac_of_bf16_peak": P * W_FLOP_PER_PT / (mlp_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+    }
+
+    # ---- CPU baseline (oracle, torch-op restatement) on a bounded sample ---------------------------
+    cpu = None
+    parity = None
+    if not args.no_cpu_baseline and world == 1:
+        from oracle import torch_ops as TO
+        ns = min(args.cpu_sample_images, B)
+        cq = inp["query"][:ns].cpu()
+        ci = [m[:ns].cpu() for m in inp["img_maps"]]
+        cv = [m[:ns].cpu() for m in inp["vox_maps"]]
+        ct = inp["trans_mat"][:ns].cpu()
+        cw = {k: v.cpu() for k, v in inp["weights"].items()}
+        if inp["map_size"] == 137:
+            cores = torch.get_num_threads()
+            TO.list_query(cq, ci, cv, ct, cw)                       # warm-up
+            times = []
+            for _ in range(3):
+                c0 = time.perf_counter()
+                ref = TO.list_query(cq, ci, cv, ct, cw)
+                times.append(time.perf_counter() - c0)
+            med = sorted(times)[1]
+            cpu = {"value": ns * N / med, "unit": "query-points/s", "cores": cores, "kind": "port",
+                   "sample": f"{ns} of {B} images x {N} points, oracle/torch_ops.py (the reference's torch "
+                             f"op sequence, fp32, no_grad), median of 3 after 1 warm-up, torch "
+                             f"{torch.__version__}, os.cpu_count()={os.cpu_count()}"}
+            parity = float((sdf[:ns].cpu() - ref).abs().max())
+
+    out = {
+        "metric": "SDF query-points/sec (B=8, N=20k, 224^2)" if args.workload.endswith("n20k_224")
+                  else "SDF query-points/sec",
+        "value": value, "unit": "query-points/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": args.workload, "images_per_gpu": B, "points_per_image": N,
+                   "global_points_per_step": world * P, "precision": args.precision,
+                   "mlp_arithmetic": "bf16 hi/lo split operands, 3 MFMA products per MAC, fp32 accumulate"
+                   if terms == 3 else "bf16 operands, fp32 accumulate",
+                   "gather_arithmetic": "fp32", "inputs": "reference layout (NCHW/NCDHW fp32) resident in HBM; "
+                   "layout hand-off + weight repack inside the timed step",
+                   "parallelism": f"batch-sharded x{world}" + (" + RCCL all-gather of sdf" if world > 1 else "")},
+        "roofline": roof,
+        "cpu_baseline": cpu,
+        "stage_ms": stage_ms,
+        "path_rates": path,
+        "parity_max_abs_err_vs_cpu": parity,
+        "speedup_vs_cpu": (value / cpu["value"]) if cpu else None,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

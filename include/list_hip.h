@@ -1,0 +1,196 @@
+/*
+ * list_hip.h -- C ABI of the MI355X (gfx950) implementation of LIST's SDF query hot path.
+ *
+ * The reference (robotic-vision-lab/Learning-Implicitly-From-Spatial-Transformers-Network)
+ * has no FFI layer: its boundary for this path is the Python nn.Module API.  Each entry point
+ * below replaces one group of PyTorch op call sites of the reference and is what a binding
+ * (ctypes / torch extension) for that path calls; INTEGRATION.md shows the binding.
+ *
+ * Conventions (all entry points)
+ *   - plain C, POD structs, raw DEVICE pointers, explicit shapes and ELEMENT strides;
+ *   - the caller owns every buffer (inputs, outputs, workspace): nothing is allocated,
+ *     freed or retained by the library, no hipMalloc/hipFree/sync inside (graph-capture safe);
+ *   - work is enqueued on the caller's stream (hipStream_t passed as void*), asynchronously;
+ *   - the device is the caller's current device (hipSetDevice before the call);
+ *   - return LIST_OK (0) or a negative error code; never throws, never aborts;
+ *     list_last_error() returns a thread-local description of the last failure;
+ *   - re-entrant and thread-safe: no global mutable state besides the thread-local
+ *     error string.
+ */
+#ifndef LIST_HIP_H
+#define LIST_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LIST_ABI_VERSION 1
+
+#define LIST_N_IMG_LEVELS 5   /* ResEncoder feature maps, network/modules.py:1067 */
+#define LIST_N_VOX_LEVELS 6   /* VoxelEncoder2 feature maps, network/modules.py:425-442 */
+#define LIST_N_STENCIL 7      /* displacement stencil, network/modules.py:205-214 */
+
+enum ListStatus {
+  LIST_OK = 0,
+  LIST_ERR_ARG = -1,         /* null pointer / bad enum / bad struct */
+  LIST_ERR_SHAPE = -2,       /* shape or stride the kernels do not support */
+  LIST_ERR_WORKSPACE = -3,   /* workspace or output buffer too small */
+  LIST_ERR_HIP = -4,         /* a HIP launch failed; see list_last_error() */
+  LIST_ERR_UNSUPPORTED = -5
+};
+
+/* Arithmetic of the implicit MLP (the gathers are always fp32):
+ *   BF16X3 : operands split into bf16 hi+lo, 3 MFMA products per MAC, fp32 accumulate
+ *            (|err| ~ 1e-5 of fp32; the default, meets the 1e-4 parity bound);
+ *   BF16   : hi part only, 1 MFMA per MAC (|err| ~ 1e-3, stated tolerance 5e-3). */
+enum ListPrecision { LIST_PREC_BF16X3 = 0, LIST_PREC_BF16 = 1 };
+
+/* One 2-D feature map [B,C,H,W] float32 with element strides (NCHW or channels-last). */
+typedef struct ListMap2D {
+  const float* data;
+  int32_t C, H, W;
+  int64_t sb, sc, sh, sw;
+} ListMap2D;
+
+/* One 3-D feature map [B,C,D,H,W] float32 with element strides. */
+typedef struct ListMap3D {
+  const float* data;
+  int32_t C, D, H, W;
+  int64_t sb, sc, sd, sh, sw;
+} ListMap3D;
+
+/* A voxel level in the layout the gather kernels read: per image [D][H][W][C] contiguous. */
+typedef struct ListVoxLevel {
+  const float* data;
+  int32_t C, D, H, W;
+  int64_t image_stride;      /* elements between images */
+} ListVoxLevel;
+
+/* MLP parameters in the REFERENCE layout (state_dict of VoxelDecoder.fc,
+ * network/modules.py:196-200; Conv1d weights [out,in,1] are [out,in] row-major). */
+typedef struct ListMlpWeights {
+  const float* w0; const float* b0;   /* fc_0  : [H1, F],  [H1]   F = 7*sum(C_vox)+C_img+3 */
+  const float* w1; const float* b1;   /* fc_1  : [H2, H1], [H2] */
+  const float* w2; const float* b2;   /* fc_2  : [H3, H2], [H3] */
+  const float* w3; const float* b3;   /* fc_out: [1, H3],  [1]  */
+  int32_t F, H1, H2, H3;
+  int32_t vox_C[LIST_N_VOX_LEVELS];   /* channel count per voxel level (feature order k=c*7+j) */
+  int32_t img_C;                      /* total perceptual channels (1024) */
+} ListMlpWeights;
+
+/* ---------------------------------------------------------------------------------------
+ * list_prep_img_maps -- replaces F.interpolate(x_i, 137, bilinear, align_corners=True) x5
+ * (network/modules.py:26-35) and fixes the layout: writes ONE channels-last map
+ * out[B][map_size][map_size][sum C_i] (channel order = concatenation order of modules.py:53).
+ * Returns LIST_OK or an error.  Required out size: list_img_map_bytes().
+ */
+size_t list_img_map_bytes(const ListMap2D maps[LIST_N_IMG_LEVELS], int32_t B, int32_t map_size);
+int list_prep_img_maps(const ListMap2D maps[LIST_N_IMG_LEVELS], int32_t B, int32_t map_size,
+                       float* out, size_t out_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * list_prep_vox_maps -- layout hand-off for F.grid_sample 3-D (network/modules.py:263-265):
+ * converts each [B,C,D,H,W] map to per-image [D][H][W][C].  A level that already has that
+ * layout (channels_last_3d strides, or C == 1 with contiguous D,H,W) is used in place and
+ * costs nothing.  levels_out[] (host memory) receives the descriptors for list_sdf_query_fwd.
+ */
+size_t list_vox_pack_bytes(const ListMap3D maps[LIST_N_VOX_LEVELS], int32_t B);
+int list_prep_vox_maps(const ListMap3D maps[LIST_N_VOX_LEVELS], int32_t B, float* pack,
+                       size_t pack_bytes, ListVoxLevel levels_out[LIST_N_VOX_LEVELS], void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * list_prep_mlp_weights -- one-off repack of the Conv1d(k=1) parameters
+ * (network/modules.py:196-200): fc_0 columns permuted from the reference feature order
+ * (k = c*7+j | perceptual | xyz, modules.py:270-275) to the gather order, K padded,
+ * bf16 hi/lo split.  Call again whenever the parameters change.
+ */
+size_t list_packed_mlp_bytes(const ListMlpWeights* w);
+int list_prep_mlp_weights(const ListMlpWeights* w, void* packed, size_t packed_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * list_sdf_query_fwd -- the fused hot path: LIST.forward lines network/models.py:91-97, i.e.
+ * PerceptualPooling.forward (modules.py:37-53, on the prepared 137^2 map) +
+ * VoxelDecoder2.forward (modules.py:255-282).  sdf[b][n] for every query point.
+ */
+typedef struct ListQueryArgs {
+  int32_t B, N;                         /* images, query points per image */
+  const float* query;                   /* [B,N,3] */
+  int64_t q_sb, q_sn, q_sc;             /* element strides of query */
+  int32_t perm[3];                      /* p[i] = scale * query[..., perm[i]]; {2,1,0}, 2.0 for */
+  float scale;                          /*   raw queries (models.py:91-92); {0,1,2}, 1.0 if done */
+  const float* trans_mat;               /* [B,4,3] contiguous (models.py:86) */
+  const float* img_map;                 /* output of list_prep_img_maps, or NULL with percep_feat */
+  int32_t map_size;                     /* 137 */
+  int32_t img_C;                        /* 1024 */
+  float clamp_hi;                       /* 136.0 (hard-coded in modules.py:43) */
+  const float* percep_feat;             /* optional pre-pooled features [B,img_C,N] instead of */
+  int64_t pf_sb, pf_sc, pf_sn;          /*   img_map (VoxelDecoder2.forward's 3rd argument) */
+  ListVoxLevel vox[LIST_N_VOX_LEVELS];  /* from list_prep_vox_maps */
+  const void* packed_mlp;               /* from list_prep_mlp_weights */
+  int32_t F, H1, H2, H3;                /* must match the packed weights */
+  float* sdf;                           /* [B,N] contiguous, output */
+  void* workspace; size_t workspace_bytes;   /* >= list_query_workspace_bytes(B*N) */
+  int32_t precision;                    /* enum ListPrecision */
+  void* const* stage_events;            /* optional: LIST_N_STAGES hipEvent_t handles (host array), */
+                                        /*   recorded on the stream at the stage boundaries below   */
+} ListQueryArgs;
+
+/* stage boundaries recorded into ListQueryArgs.stage_events (per row chunk; a later chunk
+ * re-records, so time single-chunk calls) */
+enum ListStage {
+  LIST_STAGE_BEGIN = 0,   /* before the first kernel */
+  LIST_STAGE_VOX = 1,     /* after the voxel-level gathers            (modules.py:256-265) */
+  LIST_STAGE_IMG = 2,     /* after the perceptual gather + tail       (modules.py:37-52, 257) */
+  LIST_STAGE_FC0 = 3,     /* after fc_0 + ReLU                         (modules.py:276) */
+  LIST_STAGE_FC1 = 4,     /* after fc_1 + ReLU                         (modules.py:277) */
+  LIST_STAGE_FC2 = 5,     /* after fc_2 + ReLU + fc_out -> sdf         (modules.py:278-281) */
+  LIST_N_STAGES = 6
+};
+
+size_t list_query_workspace_bytes(int64_t n_points, int32_t F, int32_t H1, int32_t H2, int32_t H3);
+int list_sdf_query_fwd(const ListQueryArgs* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * list_percep_pool_fwd -- PerceptualPooling.forward alone (network/modules.py:37-53) for
+ * callers that need the reference's materialised tensor: out[B][img_C][N] (= [B,1024,1,N]).
+ */
+typedef struct ListPoolArgs {
+  int32_t B, N;
+  const float* pc; int64_t p_sb, p_sn, p_sc;   /* [B,N,3] (already permuted/scaled) */
+  const float* trans_mat;                       /* [B,4,3] contiguous */
+  const float* img_map; int32_t map_size, img_C;
+  float clamp_hi;
+  float* out;                                   /* [B,img_C,N] contiguous */
+} ListPoolArgs;
+int list_percep_pool_fwd(const ListPoolArgs* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * list_gather_features_fwd -- test/diagnostic entry: the gathered feature matrix in the
+ * REFERENCE order and layout, out[B][F][N] float32 (= torch.cat at modules.py:275).
+ * Uses the same gather kernels as list_sdf_query_fwd (values are hi+lo of the bf16 split,
+ * i.e. fp32 rounded to 16 significant bits).
+ */
+int list_gather_features_fwd(const ListQueryArgs* args, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * list_gemm_nt -- test/diagnostic entry for the MFMA kernel used by the MLP:
+ * out[M][N] = act(A[M][K] . W[N][K]^T + bias), A and W given as bf16 hi/lo planes
+ * (lo may be NULL with LIST_PREC_BF16).  M % 256 == 0, N % 256 == 0, K % 32 == 0.
+ */
+int list_gemm_nt(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo,
+                 const float* bias, float* out, int32_t M, int32_t N, int32_t K, int32_t relu,
+                 int32_t precision, void* stream);
+
+/* fp32 -> bf16 hi/lo planes (round-to-nearest-even; lo = bf16(x - hi)). n % 4 == 0. */
+int list_split_bf16(const float* x, void* hi, void* lo, int64_t n, void* stream);
+
+const char* list_last_error(void);
+int list_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIST_HIP_H */

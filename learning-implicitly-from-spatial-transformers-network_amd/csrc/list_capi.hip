@@ -1,0 +1,356 @@
+// C ABI (include/list_hip.h): argument validation, workspace carving, launch sequencing.
+// No allocation, no synchronisation, no global mutable state (thread-local error text only).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "list_common.h"
+
+using namespace list;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+  return fail(LIST_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+constexpr int64_t kMaxChunkRows = 262144;     // bounds the workspace (~4.6 GB) for huge queries
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+bool vox_in_place(const ListMap3D& m, ListVoxLevel* lv) {
+  const int64_t C = m.C, W = m.W, H = m.H;
+  lv->C = m.C; lv->D = m.D; lv->H = m.H; lv->W = m.W;
+  if (m.C == 1) {
+    if (m.sw == 1 && m.sh == W && m.sd == H * W) { lv->data = m.data; lv->image_stride = m.sb; return true; }
+    return false;
+  }
+  if (m.sc == 1 && m.sw == C && m.sh == W * C && m.sd == H * W * C && aligned16(m.data) &&
+      (m.sb % 4) == 0) {
+    lv->data = m.data; lv->image_stride = m.sb; return true;
+  }
+  return false;
+}
+
+int check_query_common(const ListQueryArgs* a, FeatLayout* L) {
+  if (!a) return fail(LIST_ERR_ARG, "args is NULL");
+  if (a->B <= 0 || a->N <= 0) return fail(LIST_ERR_SHAPE, "B=%d N=%d must be positive", a->B, a->N);
+  if (!a->query || !a->workspace) return fail(LIST_ERR_ARG, "query/workspace is NULL");
+  for (int i = 0; i < 3; ++i)
+    if (a->perm[i] < 0 || a->perm[i] > 2) return fail(LIST_ERR_ARG, "perm[%d]=%d", i, a->perm[i]);
+  int32_t vc[LIST_N_VOX_LEVELS];
+  for (int l = 0; l < LIST_N_VOX_LEVELS; ++l) {
+    const ListVoxLevel& v = a->vox[l];
+    if (!v.data || v.D < 1 || v.H < 1 || v.W < 1)
+      return fail(LIST_ERR_SHAPE, "voxel level %d: bad descriptor", l);
+    if ((int64_t)v.D * v.H * v.W * v.C >= (int64_t)1 << 31)
+      return fail(LIST_ERR_SHAPE, "voxel level %d: image larger than 2^31 elements", l);
+    if (v.C != 1 && (!aligned16(v.data) || (v.image_stride % 4) != 0))
+      return fail(LIST_ERR_SHAPE, "voxel level %d: data must be 16-byte aligned", l);
+    if (v.C != 1 && (v.C > 256 || (v.C & (v.C - 1)) != 0 || v.C < 4))
+      return fail(LIST_ERR_UNSUPPORTED, "voxel level %d: C=%d (need 1 or a power of two in 4..256)", l, v.C);
+    vc[l] = v.C;
+  }
+  if (!make_layout(vc, a->img_C, L)) return fail(LIST_ERR_UNSUPPORTED, "unsupported channel counts");
+  if (a->percep_feat == nullptr) {
+    if (!a->img_map || !a->trans_mat) return fail(LIST_ERR_ARG, "img_map/trans_mat is NULL");
+    if (!aligned16(a->img_map)) return fail(LIST_ERR_SHAPE, "img_map must be 16-byte aligned");
+    if (a->map_size < 2) return fail(LIST_ERR_SHAPE, "map_size=%d", a->map_size);
+    if ((int64_t)a->map_size * a->map_size * a->img_C >= (int64_t)1 << 31)
+      return fail(LIST_ERR_SHAPE, "image map larger than 2^31 elements");
+  }
+  return LIST_OK;
+}
+
+GatherParams make_gather(const ListQueryArgs* a, const FeatLayout& L, const Workspace& ws,
+                         int64_t p_begin, int n_valid, int rows) {
+  GatherParams g;
+  g.query = a->query; g.q_sb = a->q_sb; g.q_sn = a->q_sn; g.q_sc = a->q_sc;
+  g.perm0 = a->perm[0]; g.perm1 = a->perm[1]; g.perm2 = a->perm[2]; g.scale = a->scale;
+  g.N = a->N; g.p_begin = p_begin; g.n_valid = n_valid; g.rows = rows;
+  g.x_hi = (unsigned short*)((char*)a->workspace + ws.x_hi);
+  g.x_lo = (unsigned short*)((char*)a->workspace + ws.x_lo);
+  g.Kp = L.Kp;
+  return g;
+}
+
+// rows the given workspace can hold (multiple of kRowTile, capped at the request), or 0
+int64_t chunk_rows_for(size_t bytes, int64_t P, int Kp, int H1, int H2) {
+  int64_t want = (P + kRowTile - 1) / kRowTile * kRowTile;
+  if (want > kMaxChunkRows) want = kMaxChunkRows;
+  int64_t fit = (int64_t)(bytes / workspace_row_bytes(Kp, H1, H2)) / kRowTile * kRowTile;
+  if (fit > want) fit = want;
+  while (fit >= kRowTile && workspace_layout(fit, Kp, H1, H2).total > bytes) fit -= kRowTile;
+  return fit >= kRowTile ? fit : 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* list_last_error(void) { return g_err; }
+int list_abi_version(void) { return LIST_ABI_VERSION; }
+
+// ------------------------------------------------------------------------------------------ 2-D maps
+size_t list_img_map_bytes(const ListMap2D maps[LIST_N_IMG_LEVELS], int32_t B, int32_t map_size) {
+  if (!maps || B <= 0 || map_size <= 0) return 0;
+  size_t Ct = 0;
+  for (int i = 0; i < LIST_N_IMG_LEVELS; ++i) Ct += (size_t)maps[i].C;
+  return (size_t)B * map_size * map_size * Ct * sizeof(float);
+}
+
+int list_prep_img_maps(const ListMap2D maps[LIST_N_IMG_LEVELS], int32_t B, int32_t map_size,
+                       float* out, size_t out_bytes, void* stream) {
+  if (!maps || !out) return fail(LIST_ERR_ARG, "maps/out is NULL");
+  if (B <= 0 || map_size < 2 || map_size > 320)
+    return fail(LIST_ERR_SHAPE, "B=%d map_size=%d (need 2..320)", B, map_size);
+  int Ct = 0;
+  for (int i = 0; i < LIST_N_IMG_LEVELS; ++i) {
+    const ListMap2D& m = maps[i];
+    if (!m.data || m.C < 1 || m.H < 1 || m.W < 1)
+      return fail(LIST_ERR_SHAPE, "image level %d: bad descriptor", i);
+    Ct += m.C;
+  }
+  if (Ct % 4) return fail(LIST_ERR_UNSUPPORTED, "total image channels %d not a multiple of 4", Ct);
+  if (out_bytes < list_img_map_bytes(maps, B, map_size))
+    return fail(LIST_ERR_WORKSPACE, "out buffer too small: %zu < %zu", out_bytes,
+                list_img_map_bytes(maps, B, map_size));
+  if ((int64_t)B * map_size > 2147483647LL) return fail(LIST_ERR_SHAPE, "grid too large");
+  hipError_t e = launch_prep_img(maps, B, map_size, Ct, out, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "prep_img launch");
+  return LIST_OK;
+}
+
+// ------------------------------------------------------------------------------------------ 3-D maps
+size_t list_vox_pack_bytes(const ListMap3D maps[LIST_N_VOX_LEVELS], int32_t B) {
+  if (!maps || B <= 0) return 0;
+  size_t total = 0;
+  for (int l = 0; l < LIST_N_VOX_LEVELS; ++l) {
+    ListVoxLevel lv;
+    if (vox_in_place(maps[l], &lv)) continue;
+    total += align_up((size_t)B * maps[l].C * maps[l].D * maps[l].H * maps[l].W * sizeof(float), 256);
+  }
+  return total;
+}
+
+int list_prep_vox_maps(const ListMap3D maps[LIST_N_VOX_LEVELS], int32_t B, float* pack,
+                       size_t pack_bytes, ListVoxLevel levels_out[LIST_N_VOX_LEVELS], void* stream) {
+  if (!maps || !levels_out) return fail(LIST_ERR_ARG, "maps/levels_out is NULL");
+  if (B <= 0 || B > 65535) return fail(LIST_ERR_SHAPE, "B=%d", B);
+  const size_t need = list_vox_pack_bytes(maps, B);
+  if (need > 0 && (!pack || pack_bytes < need))
+    return fail(LIST_ERR_WORKSPACE, "pack buffer too small: %zu < %zu", pack_bytes, need);
+  if (need > 0 && !aligned16(pack)) return fail(LIST_ERR_SHAPE, "pack must be 16-byte aligned");
+  size_t off = 0;
+  for (int l = 0; l < LIST_N_VOX_LEVELS; ++l) {
+    const ListMap3D& m = maps[l];
+    if (!m.data || m.C < 1 || m.D < 1 || m.H < 1 || m.W < 1)
+      return fail(LIST_ERR_SHAPE, "voxel level %d: bad descriptor", l);
+    if ((int64_t)m.D * m.H * m.W * m.C >= (int64_t)1 << 31)
+      return fail(LIST_ERR_SHAPE, "voxel level %d: image larger than 2^31 elements", l);
+    if (vox_in_place(m, &levels_out[l])) continue;
+    float* dst = (float*)((char*)pack + off);
+    hipError_t e = launch_transpose_vox(m, B, dst, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "transpose_vox launch");
+    levels_out[l].data = dst;
+    levels_out[l].C = m.C; levels_out[l].D = m.D; levels_out[l].H = m.H; levels_out[l].W = m.W;
+    levels_out[l].image_stride = (int64_t)m.C * m.D * m.H * m.W;
+    off += align_up((size_t)B * m.C * m.D * m.H * m.W * sizeof(float), 256);
+  }
+  return LIST_OK;
+}
+
+// ------------------------------------------------------------------------------------------ weights
+static int weights_layout(const ListMlpWeights* w, FeatLayout* L) {
+  if (!w) return fail(LIST_ERR_ARG, "weights is NULL");
+  if (!w->w0 || !w->b0 || !w->w1 || !w->b1 || !w->w2 || !w->b2 || !w->w3 || !w->b3)
+    return fail(LIST_ERR_ARG, "a weight pointer is NULL");
+  if (!make_layout(w->vox_C, w->img_C, L)) return fail(LIST_ERR_UNSUPPORTED, "unsupported channel counts");
+  if (L->F != w->F) return fail(LIST_ERR_SHAPE, "F=%d but channels give %d", w->F, L->F);
+  if (w->H1 % 256 || w->H2 % 256 || w->H3 != 256 || w->H1 <= 0 || w->H2 <= 0)
+    return fail(LIST_ERR_UNSUPPORTED, "hidden sizes %d/%d/%d (need H1,H2 multiples of 256, H3 = 256)",
+                w->H1, w->H2, w->H3);
+  return LIST_OK;
+}
+
+size_t list_packed_mlp_bytes(const ListMlpWeights* w) {
+  FeatLayout L;
+  if (weights_layout(w, &L) != LIST_OK) return 0;
+  return packed_mlp_layout(L.Kp, w->H1, w->H2, w->H3).total;
+}
+
+int list_prep_mlp_weights(const ListMlpWeights* w, void* packed, size_t packed_bytes, void* stream) {
+  FeatLayout L;
+  int rc = weights_layout(w, &L);
+  if (rc != LIST_OK) return rc;
+  const PackedMlp P = packed_mlp_layout(L.Kp, w->H1, w->H2, w->H3);
+  if (!packed || packed_bytes < P.total)
+    return fail(LIST_ERR_WORKSPACE, "packed buffer too small: %zu < %zu", packed_bytes, P.total);
+  if (!aligned16(packed) || !aligned16(w->w1) || !aligned16(w->w2))
+    return fail(LIST_ERR_SHAPE, "packed/w1/w2 must be 16-byte aligned");
+  hipError_t e = launch_prep_weights(*w, L, P, (char*)packed, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "prep_weights launch");
+  return LIST_OK;
+}
+
+// ------------------------------------------------------------------------------------------ query
+size_t list_query_workspace_bytes(int64_t n_points, int32_t F, int32_t H1, int32_t H2, int32_t H3) {
+  (void)H3;
+  if (n_points <= 0 || F <= 0 || H1 <= 0 || H2 <= 0) return 0;
+  const int Kp = (F + kKTile - 1) / kKTile * kKTile;
+  int64_t rows = (n_points + kRowTile - 1) / kRowTile * kRowTile;
+  if (rows > kMaxChunkRows) rows = kMaxChunkRows;
+  return workspace_layout(rows, Kp, H1, H2).total;
+}
+
+int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
+  FeatLayout L;
+  int rc = check_query_common(a, &L);
+  if (rc != LIST_OK) return rc;
+  if (!a->sdf || !a->packed_mlp) return fail(LIST_ERR_ARG, "sdf/packed_mlp is NULL");
+  if (a->F != L.F) return fail(LIST_ERR_SHAPE, "F=%d but channels give %d", a->F, L.F);
+  if (a->H1 % 256 || a->H2 % 256 || a->H3 != 256 || a->H1 <= 0 || a->H2 <= 0)
+    return fail(LIST_ERR_UNSUPPORTED, "hidden sizes %d/%d/%d", a->H1, a->H2, a->H3);
+  if (a->precision != LIST_PREC_BF16X3 && a->precision != LIST_PREC_BF16)
+    return fail(LIST_ERR_ARG, "precision=%d", a->precision);
+  if (!aligned16(a->workspace)) return fail(LIST_ERR_SHAPE, "workspace must be 16-byte aligned");
+  const int64_t P = (int64_t)a->B * a->N;
+  const int64_t rows = chunk_rows_for(a->workspace_bytes, P, L.Kp, a->H1, a->H2);
+  if (rows < kRowTile)
+    return fail(LIST_ERR_WORKSPACE, "workspace of %zu bytes cannot hold one %d-row tile",
+                a->workspace_bytes, kRowTile);
+  const Workspace ws = workspace_layout(rows, L.Kp, a->H1, a->H2);
+  const PackedMlp pk = packed_mlp_layout(L.Kp, a->H1, a->H2, a->H3);
+  const char* wp = (const char*)a->packed_mlp;
+  char* wsb = (char*)a->workspace;
+  const int terms = a->precision == LIST_PREC_BF16X3 ? 3 : 1;
+  hipStream_t s = (hipStream_t)stream;
+
+  for (int64_t p0 = 0; p0 < P; p0 += rows) {
+    const int n_valid = (int)((P - p0 < rows) ? (P - p0) : rows);
+    const int crow = (n_valid + kRowTile - 1) / kRowTile * kRowTile;
+    GatherParams g = make_gather(a, L, ws, p0, n_valid, crow);
+    auto mark = [&](int stage) {
+      if (a->stage_events && a->stage_events[stage])
+        (void)hipEventRecord((hipEvent_t)a->stage_events[stage], s);
+    };
+    mark(LIST_STAGE_BEGIN);
+    hipError_t e = launch_gather(g, L, *a, s);
+    if (e != hipSuccess) return hip_fail(e, "gather launch");
+    mark(LIST_STAGE_IMG);
+
+    GemmParams gp;
+    memset(&gp, 0, sizeof(gp));
+    // fc_0 + ReLU
+    gp.a_hi = wsb + ws.x_hi; gp.a_lo = wsb + ws.x_lo;
+    gp.w_hi = wp + pk.w0_hi; gp.w_lo = wp + pk.w0_lo;
+    gp.bias = (const float*)(wp + pk.b0);
+    gp.M = crow; gp.N = a->H1; gp.K = L.Kp;
+    gp.out_hi = (unsigned short*)(wsb + ws.h1_hi);
+    gp.out_lo = terms == 3 ? (unsigned short*)(wsb + ws.h1_lo) : nullptr;
+    gp.ldo = a->H1;
+    e = launch_gemm(gp, terms, EPI_RELU_SPLIT, s);
+    if (e != hipSuccess) return hip_fail(e, "fc_0 launch");
+    mark(LIST_STAGE_FC0);
+    // fc_1 + ReLU
+    gp.a_hi = wsb + ws.h1_hi; gp.a_lo = wsb + ws.h1_lo;
+    gp.w_hi = wp + pk.w1_hi; gp.w_lo = wp + pk.w1_lo;
+    gp.bias = (const float*)(wp + pk.b1);
+    gp.N = a->H2; gp.K = a->H1;
+    gp.out_hi = (unsigned short*)(wsb + ws.h2_hi);
+    gp.out_lo = terms == 3 ? (unsigned short*)(wsb + ws.h2_lo) : nullptr;
+    gp.ldo = a->H2;
+    e = launch_gemm(gp, terms, EPI_RELU_SPLIT, s);
+    if (e != hipSuccess) return hip_fail(e, "fc_1 launch");
+    mark(LIST_STAGE_FC1);
+    // fc_2 + ReLU + fc_out
+    gp.a_hi = wsb + ws.h2_hi; gp.a_lo = wsb + ws.h2_lo;
+    gp.w_hi = wp + pk.w2_hi; gp.w_lo = wp + pk.w2_lo;
+    gp.bias = (const float*)(wp + pk.b2);
+    gp.N = a->H3; gp.K = a->H2;
+    gp.out_hi = nullptr; gp.out_lo = nullptr;
+    gp.w3 = (const float*)(wp + pk.w3); gp.b3 = (const float*)(wp + pk.b3);
+    gp.sdf = a->sdf + p0; gp.n_valid = n_valid;
+    e = launch_gemm(gp, terms, EPI_RELU_DOT, s);
+    if (e != hipSuccess) return hip_fail(e, "fc_2/fc_out launch");
+    mark(LIST_STAGE_FC2);
+  }
+  return LIST_OK;
+}
+
+int list_gather_features_fwd(const ListQueryArgs* a, float* out, void* stream) {
+  FeatLayout L;
+  int rc = check_query_common(a, &L);
+  if (rc != LIST_OK) return rc;
+  if (!out) return fail(LIST_ERR_ARG, "out is NULL");
+  const int64_t P = (int64_t)a->B * a->N;
+  const int H1 = a->H1 > 0 ? a->H1 : 512, H2 = a->H2 > 0 ? a->H2 : 256;
+  const int64_t rows = chunk_rows_for(a->workspace_bytes, P, L.Kp, H1, H2);
+  if (rows < kRowTile) return fail(LIST_ERR_WORKSPACE, "workspace too small");
+  const Workspace ws = workspace_layout(rows, L.Kp, H1, H2);
+  hipStream_t s = (hipStream_t)stream;
+  for (int64_t p0 = 0; p0 < P; p0 += rows) {
+    const int n_valid = (int)((P - p0 < rows) ? (P - p0) : rows);
+    const int crow = (n_valid + kRowTile - 1) / kRowTile * kRowTile;
+    GatherParams g = make_gather(a, L, ws, p0, n_valid, crow);
+    hipError_t e = launch_gather(g, L, *a, s);
+    if (e != hipSuccess) return hip_fail(e, "gather launch");
+    e = launch_features_out(g, L, out, a->B, s);
+    if (e != hipSuccess) return hip_fail(e, "features_out launch");
+  }
+  return LIST_OK;
+}
+
+int list_percep_pool_fwd(const ListPoolArgs* a, void* stream) {
+  if (!a) return fail(LIST_ERR_ARG, "args is NULL");
+  if (!a->pc || !a->trans_mat || !a->img_map || !a->out) return fail(LIST_ERR_ARG, "NULL pointer");
+  if (a->B <= 0 || a->N <= 0 || a->map_size < 2 || a->img_C <= 0 || a->img_C % 4)
+    return fail(LIST_ERR_SHAPE, "B=%d N=%d map_size=%d img_C=%d", a->B, a->N, a->map_size, a->img_C);
+  if (!aligned16(a->img_map)) return fail(LIST_ERR_SHAPE, "img_map must be 16-byte aligned");
+  if ((int64_t)a->map_size * a->map_size * a->img_C >= (int64_t)1 << 31)
+    return fail(LIST_ERR_SHAPE, "image map larger than 2^31 elements");
+  hipError_t e = launch_percep_pool(*a, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "percep_pool launch");
+  return LIST_OK;
+}
+
+// ------------------------------------------------------------------------------------------ diagnostics
+int list_gemm_nt(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo,
+                 const float* bias, float* out, int32_t M, int32_t N, int32_t K, int32_t relu,
+                 int32_t precision, void* stream) {
+  if (!a_hi || !w_hi || !out) return fail(LIST_ERR_ARG, "NULL pointer");
+  if (precision == LIST_PREC_BF16X3 && (!a_lo || !w_lo)) return fail(LIST_ERR_ARG, "lo planes missing");
+  if (M <= 0 || M % 256 || N <= 0 || N % 256 || K <= 0 || K % 32)
+    return fail(LIST_ERR_SHAPE, "M=%d N=%d K=%d (need M,N %% 256 == 0, K %% 32 == 0)", M, N, K);
+  if (!aligned16(a_hi) || !aligned16(w_hi) || (a_lo && !aligned16(a_lo)) || (w_lo && !aligned16(w_lo)))
+    return fail(LIST_ERR_SHAPE, "operands must be 16-byte aligned");
+  GemmParams gp;
+  memset(&gp, 0, sizeof(gp));
+  gp.a_hi = (const char*)a_hi; gp.a_lo = (const char*)a_lo;
+  gp.w_hi = (const char*)w_hi; gp.w_lo = (const char*)w_lo;
+  gp.bias = bias; gp.M = M; gp.N = N; gp.K = K; gp.out_f32 = out; gp.relu = relu;
+  hipError_t e = launch_gemm(gp, precision == LIST_PREC_BF16X3 ? 3 : 1, EPI_F32, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "gemm launch");
+  return LIST_OK;
+}
+
+int list_split_bf16(const float* x, void* hi, void* lo, int64_t n, void* stream) {
+  if (!x || !hi) return fail(LIST_ERR_ARG, "NULL pointer");
+  if (n <= 0 || n % 4) return fail(LIST_ERR_SHAPE, "n=%lld must be a positive multiple of 4", (long long)n);
+  if (!aligned16(x)) return fail(LIST_ERR_SHAPE, "x must be 16-byte aligned");
+  hipError_t e = launch_split(x, (unsigned short*)hi, (unsigned short*)lo, n, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "split launch");
+  return LIST_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,171 @@
+// Internal definitions shared by the gfx950 kernels of the LIST SDF query path.
+// Not part of the C ABI (that is include/list_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "list_hip.h"
+
+namespace list {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int kRowTile = 256;       // GEMM BM: workspace rows are padded to this
+constexpr int kKTile = 32;          // GEMM BK: feature columns are padded to this
+constexpr int kGatherRows = 64;     // query points per gather workgroup
+constexpr float kDisp = 0.0722f;    // stencil displacement, network/modules.py:205
+
+// ---- bf16 hi/lo split -------------------------------------------------------------------
+// hi = bf16_rne(x), lo = bf16_rne(x - hi): x ~ hi + lo to 16 significant bits.
+__device__ __forceinline__ unsigned short f2bf(float x) {
+  return __builtin_bit_cast(unsigned short, (__bf16)x);     // v_cvt_pk_bf16_f32, NaN-preserving
+}
+__device__ __forceinline__ float bf2f(unsigned short h) {
+  return __builtin_bit_cast(float, (unsigned)h << 16);
+}
+__device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
+  const unsigned short h0 = f2bf(v.x), h1 = f2bf(v.y), h2 = f2bf(v.z), h3 = f2bf(v.w);
+  const unsigned short l0 = f2bf(v.x - bf2f(h0)), l1 = f2bf(v.y - bf2f(h1));
+  const unsigned short l2 = f2bf(v.z - bf2f(h2)), l3 = f2bf(v.w - bf2f(h3));
+  hi = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
+  lo = make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));
+}
+
+// ---- feature layout ---------------------------------------------------------------------
+// Column order of the gathered feature matrix X[row][Kp] ("gather order"):
+//   [vector voxel levels (C%4==0): level-major, stencil j, channel c]  [perceptual img_C]
+//   [scalar voxel levels (C==1): stencil j]  [xyz]  [zero pad to a multiple of kKTile]
+// The reference order (network/modules.py:270-275) is k = (cbase_L + c)*7 + j | img | xyz;
+// fc_0's columns are permuted once (list_prep_mlp_weights) so no shuffle happens per point.
+struct FeatLayout {
+  int vox_C[LIST_N_VOX_LEVELS];
+  int vox_off[LIST_N_VOX_LEVELS];     // first column of the level in gather order
+  int vox_cbase[LIST_N_VOX_LEVELS];   // first channel of the level in the reference concat
+  int vox_ctotal;
+  int img_off, img_C;
+  int xyz_off;
+  int F;                               // 7*vox_ctotal + img_C + 3
+  int Kp;                              // F padded to kKTile
+};
+
+// returns false if a channel count is unsupported
+inline bool make_layout(const int32_t vox_C[LIST_N_VOX_LEVELS], int32_t img_C, FeatLayout* L) {
+  int cbase = 0, col = 0;
+  for (int l = 0; l < LIST_N_VOX_LEVELS; ++l) {
+    const int C = vox_C[l];
+    if (C < 1 || (C != 1 && (C % 4) != 0)) return false;
+    L->vox_C[l] = C;
+    L->vox_cbase[l] = cbase;
+    cbase += C;
+  }
+  L->vox_ctotal = cbase;
+  for (int l = 0; l < LIST_N_VOX_LEVELS; ++l)
+    if (L->vox_C[l] != 1) { L->vox_off[l] = col; col += LIST_N_STENCIL * L->vox_C[l]; }
+  if (img_C < 0 || (img_C % 4) != 0) return false;
+  L->img_off = col; L->img_C = img_C; col += img_C;
+  for (int l = 0; l < LIST_N_VOX_LEVELS; ++l)
+    if (L->vox_C[l] == 1) { L->vox_off[l] = col; col += LIST_N_STENCIL; }
+  L->xyz_off = col; col += 3;
+  L->F = col;
+  L->Kp = (col + kKTile - 1) / kKTile * kKTile;
+  return true;
+}
+
+// gather-order column -> reference feature index (or -1 for padding)
+__host__ __device__ inline int ref_index_of(const FeatLayout& L, int kp) {
+  if (kp >= L.F) return -1;
+  if (kp >= L.xyz_off) return LIST_N_STENCIL * L.vox_ctotal + L.img_C + (kp - L.xyz_off);
+  if (kp >= L.img_off && kp < L.img_off + L.img_C)
+    return LIST_N_STENCIL * L.vox_ctotal + (kp - L.img_off);
+  for (int l = 0; l < LIST_N_VOX_LEVELS; ++l) {
+    const int C = L.vox_C[l];
+    const int r = kp - L.vox_off[l];
+    if (r >= 0 && r < LIST_N_STENCIL * C) {
+      const int j = r / C, c = r - j * C;
+      return (L.vox_cbase[l] + c) * LIST_N_STENCIL + j;
+    }
+  }
+  return -1;
+}
+
+// ---- packed MLP parameters (output of list_prep_mlp_weights) --------------------------------
+struct PackedMlp {
+  size_t w0_hi, w0_lo, w1_hi, w1_lo, w2_hi, w2_lo;   // byte offsets, bf16 [N][K] row-major
+  size_t b0, b1, b2, w3, b3;                         // byte offsets, float
+  size_t total;
+};
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline PackedMlp packed_mlp_layout(int Kp, int H1, int H2, int H3) {
+  PackedMlp p;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+  p.w0_hi = take((size_t)H1 * Kp * 2); p.w0_lo = take((size_t)H1 * Kp * 2);
+  p.w1_hi = take((size_t)H2 * H1 * 2); p.w1_lo = take((size_t)H2 * H1 * 2);
+  p.w2_hi = take((size_t)H3 * H2 * 2); p.w2_lo = take((size_t)H3 * H2 * 2);
+  p.b0 = take((size_t)H1 * 4); p.b1 = take((size_t)H2 * 4); p.b2 = take((size_t)H3 * 4);
+  p.w3 = take((size_t)H3 * 4); p.b3 = take(4);
+  p.total = o;
+  return p;
+}
+
+// ---- per-chunk workspace --------------------------------------------------------------------
+struct Workspace {
+  size_t x_hi, x_lo, h1_hi, h1_lo, h2_hi, h2_lo;     // byte offsets
+  size_t total;
+};
+inline size_t workspace_row_bytes(int Kp, int H1, int H2) {
+  return (size_t)2 * 2 * ((size_t)Kp + H1 + H2);
+}
+inline Workspace workspace_layout(int64_t rows, int Kp, int H1, int H2) {
+  Workspace w;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+  w.x_hi = take((size_t)rows * Kp * 2); w.x_lo = take((size_t)rows * Kp * 2);
+  w.h1_hi = take((size_t)rows * H1 * 2); w.h1_lo = take((size_t)rows * H1 * 2);
+  w.h2_hi = take((size_t)rows * H2 * 2); w.h2_lo = take((size_t)rows * H2 * 2);
+  w.total = o;
+  return w;
+}
+
+// ---- kernel parameter blocks ----------------------------------------------------------------
+struct GatherParams {
+  const float* query; int64_t q_sb, q_sn, q_sc;
+  int perm0, perm1, perm2; float scale;
+  int N;                      // points per image
+  int64_t p_begin;            // first global point of this chunk
+  int n_valid;                // valid rows in this chunk
+  int rows;                   // padded rows (multiple of kRowTile)
+  unsigned short* x_hi; unsigned short* x_lo;
+  int Kp;
+};
+
+struct GemmParams {
+  const char* a_hi; const char* a_lo;     // [M][K] bf16
+  const char* w_hi; const char* w_lo;     // [N][K] bf16
+  const float* bias;                      // [N]
+  int M, N, K;
+  unsigned short* out_hi; unsigned short* out_lo; int ldo;   // EPI_RELU_SPLIT
+  float* out_f32; int relu;                                  // EPI_F32
+  const float* w3; const float* b3; float* sdf; int n_valid; // EPI_RELU_DOT
+};
+
+enum { EPI_RELU_SPLIT = 0, EPI_F32 = 1, EPI_RELU_DOT = 2 };
+
+// ---- launchers (defined in the .hip files) ----------------------------------------------------
+hipError_t launch_prep_img(const ListMap2D maps[LIST_N_IMG_LEVELS], int B, int map_size, int Ct,
+                           float* out, hipStream_t s);
+hipError_t launch_transpose_vox(const ListMap3D& m, int B, float* out, hipStream_t s);
+hipError_t launch_prep_weights(const ListMlpWeights& w, const FeatLayout& L, const PackedMlp& P,
+                               char* packed, hipStream_t s);
+hipError_t launch_split(const float* x, unsigned short* hi, unsigned short* lo, int64_t n,
+                        hipStream_t s);
+hipError_t launch_gather(const GatherParams& g, const FeatLayout& L, const ListQueryArgs& a,
+                         hipStream_t s);
+hipError_t launch_features_out(const GatherParams& g, const FeatLayout& L, float* out, int B,
+                               hipStream_t s);
+hipError_t launch_percep_pool(const ListPoolArgs& a, hipStream_t s);
+hipError_t launch_gemm(const GemmParams& p, int terms, int epi, hipStream_t s);
+
+}  // namespace list

@@ -1,0 +1,382 @@
+"""Host-side binding of the C ABI (include/list_hip.h) for PyTorch-ROCm tensors.
+
+PyTorch is plumbing here: device memory (caching allocator), the current HIP stream and
+`torch.distributed`.  Every compute call goes through liblist_hip.so; there is NO fallback:
+if the library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblist_hip.so")
+
+N_IMG_LEVELS = 5
+N_VOX_LEVELS = 6
+PREC_BF16X3 = 0
+PREC_BF16 = 1
+PRECISIONS = {"bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
+
+
+class ListMap2D(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("sb", C.c_int64), ("sc", C.c_int64), ("sh", C.c_int64), ("sw", C.c_int64)]
+
+
+class ListMap3D(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("C", C.c_int32), ("D", C.c_int32), ("H", C.c_int32),
+                ("W", C.c_int32), ("sb", C.c_int64), ("sc", C.c_int64), ("sd", C.c_int64),
+                ("sh", C.c_int64), ("sw", C.c_int64)]
+
+
+class ListVoxLevel(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("C", C.c_int32), ("D", C.c_int32), ("H", C.c_int32),
+                ("W", C.c_int32), ("image_stride", C.c_int64)]
+
+
+class ListMlpWeights(C.Structure):
+    _fields_ = [("w0", C.c_void_p), ("b0", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p),
+                ("w2", C.c_void_p), ("b2", C.c_void_p), ("w3", C.c_void_p), ("b3", C.c_void_p),
+                ("F", C.c_int32), ("H1", C.c_int32), ("H2", C.c_int32), ("H3", C.c_int32),
+                ("vox_C", C.c_int32 * N_VOX_LEVELS), ("img_C", C.c_int32)]
+
+
+class ListQueryArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32),
+                ("query", C.c_void_p), ("q_sb", C.c_int64), ("q_sn", C.c_int64), ("q_sc", C.c_int64),
+                ("perm", C.c_int32 * 3), ("scale", C.c_float),
+                ("trans_mat", C.c_void_p),
+                ("img_map", C.c_void_p), ("map_size", C.c_int32), ("img_C", C.c_int32),
+                ("clamp_hi", C.c_float),
+                ("percep_feat", C.c_void_p), ("pf_sb", C.c_int64), ("pf_sc", C.c_int64),
+                ("pf_sn", C.c_int64),
+                ("vox", ListVoxLevel * N_VOX_LEVELS),
+                ("packed_mlp", C.c_void_p),
+                ("F", C.c_int32), ("H1", C.c_int32), ("H2", C.c_int32), ("H3", C.c_int32),
+                ("sdf", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("precision", C.c_int32),
+                ("stage_events", C.POINTER(C.c_void_p))]
+
+
+N_STAGES = 6
+STAGE_NAMES = ("gather_vox", "gather_img_tail", "fc_0", "fc_1", "fc_2_out")
+
+
+class ListPoolArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32),
+                ("pc", C.c_void_p), ("p_sb", C.c_int64), ("p_sn", C.c_int64), ("p_sc", C.c_int64),
+                ("trans_mat", C.c_void_p),
+                ("img_map", C.c_void_p), ("map_size", C.c_int32), ("img_C", C.c_int32),
+                ("clamp_hi", C.c_float),
+                ("out", C.c_void_p)]
+
+
+EXPORTS = {
+    "list_img_map_bytes": (C.c_size_t, [C.POINTER(ListMap2D), C.c_int32, C.c_int32]),
+    "list_prep_img_maps": (C.c_int, [C.POINTER(ListMap2D), C.c_int32, C.c_int32, C.c_void_p,
+                                     C.c_size_t, C.c_void_p]),
+    "list_vox_pack_bytes": (C.c_size_t, [C.POINTER(ListMap3D), C.c_int32]),
+    "list_prep_vox_maps": (C.c_int, [C.POINTER(ListMap3D), C.c_int32, C.c_void_p, C.c_size_t,
+                                     C.POINTER(ListVoxLevel), C.c_void_p]),
+    "list_packed_mlp_bytes": (C.c_size_t, [C.POINTER(ListMlpWeights)]),
+    "list_prep_mlp_weights": (C.c_int, [C.POINTER(ListMlpWeights), C.c_void_p, C.c_size_t,
+                                        C.c_void_p]),
+    "list_query_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                                C.c_int32]),
+    "list_sdf_query_fwd": (C.c_int, [C.POINTER(ListQueryArgs), C.c_void_p]),
+    "list_percep_pool_fwd": (C.c_int, [C.POINTER(ListPoolArgs), C.c_void_p]),
+    "list_gather_features_fwd": (C.c_int, [C.POINTER(ListQueryArgs), C.c_void_p, C.c_void_p]),
+    "list_gemm_nt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                               C.c_void_p]),
+    "list_split_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "list_last_error": (C.c_char_p, []),
+    "list_abi_version": (C.c_int, []),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """dlopen liblist_hip.so and bind every symbol of include/list_hip.h.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
+                    "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for the "
+                    "LIST SDF query path.")
+            lib = C.CDLL(LIB_PATH)
+            for name, (res, args) in EXPORTS.items():
+                fn = getattr(lib, name)
+                fn.restype, fn.argtypes = res, args
+            _lib = lib
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load().list_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed ({rc}): {msg}")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32_cuda(t, name):
+    if not isinstance(t, torch.Tensor) or t.dtype != torch.float32 or not t.is_cuda:
+        raise RuntimeError(f"{name} must be a float32 CUDA/HIP tensor (got {type(t).__name__} "
+                           f"{getattr(t, 'dtype', None)} {getattr(t, 'device', None)})")
+    return t
+
+
+# ------------------------------------------------------------------------------------------------
+class PreparedImage:
+    """Channels-last resized perceptual map [B,ms,ms,Ct] (+ the sources it was built from)."""
+
+    def __init__(self, data, map_size, channels):
+        self.data, self.map_size, self.channels = data, map_size, channels
+
+
+class PreparedVoxels:
+    """Per-image [D][H][W][C] voxel levels; keeps the owning tensors alive."""
+
+    def __init__(self, levels, keepalive):
+        self.levels, self._keep = levels, keepalive
+
+    @property
+    def channels(self):
+        return [int(self.levels[i].C) for i in range(N_VOX_LEVELS)]
+
+
+class PackedMlp:
+    def __init__(self, data, F, H1, H2, H3, vox_C, img_C):
+        self.data, self.F, self.H1, self.H2, self.H3 = data, F, H1, H2, H3
+        self.vox_C, self.img_C = list(vox_C), img_C
+
+
+def prep_img_maps(img_featuremaps, map_size=137):
+    """F.interpolate x5 (+ layout) of the reference, network/modules.py:26-35."""
+    lib = load()
+    if len(img_featuremaps) != N_IMG_LEVELS:
+        raise RuntimeError(f"expected {N_IMG_LEVELS} image feature maps, got {len(img_featuremaps)}")
+    maps = (ListMap2D * N_IMG_LEVELS)()
+    B = img_featuremaps[0].shape[0]
+    Ct = 0
+    for i, t in enumerate(img_featuremaps):
+        _f32_cuda(t, f"img_featuremaps[{i}]")
+        if t.dim() != 4 or t.shape[0] != B:
+            raise RuntimeError(f"img_featuremaps[{i}] must be [B,C,H,W]")
+        maps[i] = ListMap2D(t.data_ptr(), t.shape[1], t.shape[2], t.shape[3], *t.stride())
+        Ct += t.shape[1]
+    out = torch.empty((B, map_size, map_size, Ct), dtype=torch.float32, device=img_featuremaps[0].device)
+    with torch.cuda.device(out.device):
+        _check(lib.list_prep_img_maps(maps, B, map_size, out.data_ptr(), out.numel() * 4, _stream()),
+               "list_prep_img_maps")
+    return PreparedImage(out, map_size, Ct)
+
+
+def prep_vox_maps(vox_feat):
+    """Layout hand-off for the 3-D grid_sample of network/modules.py:263-265."""
+    lib = load()
+    if len(vox_feat) != N_VOX_LEVELS:
+        raise RuntimeError(f"expected {N_VOX_LEVELS} voxel feature maps, got {len(vox_feat)}")
+    maps = (ListMap3D * N_VOX_LEVELS)()
+    B = vox_feat[0].shape[0]
+    for i, t in enumerate(vox_feat):
+        _f32_cuda(t, f"vox_feat[{i}]")
+        if t.dim() != 5 or t.shape[0] != B:
+            raise RuntimeError(f"vox_feat[{i}] must be [B,C,D,H,W]")
+        maps[i] = ListMap3D(t.data_ptr(), t.shape[1], t.shape[2], t.shape[3], t.shape[4], *t.stride())
+    need = lib.list_vox_pack_bytes(maps, B)
+    dev = vox_feat[0].device
+    pack = torch.empty((max(need, 16) // 4,), dtype=torch.float32, device=dev)
+    levels = (ListVoxLevel * N_VOX_LEVELS)()
+    with torch.cuda.device(dev):
+        _check(lib.list_prep_vox_maps(maps, B, pack.data_ptr(), pack.numel() * 4, levels, _stream()),
+               "list_prep_vox_maps")
+    return PreparedVoxels(levels, (pack, list(vox_feat)))
+
+
+def prep_mlp_weights(params, vox_C, img_C=1024):
+    """params: dict with fc_0/fc_1/fc_2/fc_out .weight/.bias (reference state_dict names,
+    network/modules.py:196-200).  Conv1d weights may be [out,in,1] or [out,in]."""
+    lib = load()
+    ts = {}
+    for name in ("fc_0", "fc_1", "fc_2", "fc_out"):
+        w = _f32_cuda(params[name + ".weight"], name + ".weight").detach()
+        b = _f32_cuda(params[name + ".bias"], name + ".bias").detach()
+        ts[name] = (w.reshape(w.shape[0], -1).contiguous(), b.contiguous())
+    w = ListMlpWeights()
+    w.w0, w.b0 = ts["fc_0"][0].data_ptr(), ts["fc_0"][1].data_ptr()
+    w.w1, w.b1 = ts["fc_1"][0].data_ptr(), ts["fc_1"][1].data_ptr()
+    w.w2, w.b2 = ts["fc_2"][0].data_ptr(), ts["fc_2"][1].data_ptr()
+    w.w3, w.b3 = ts["fc_out"][0].data_ptr(), ts["fc_out"][1].data_ptr()
+    w.F, w.H1 = ts["fc_0"][0].shape[1], ts["fc_0"][0].shape[0]
+    w.H2, w.H3 = ts["fc_1"][0].shape[0], ts["fc_2"][0].shape[0]
+    if ts["fc_1"][0].shape[1] != w.H1 or ts["fc_2"][0].shape[1] != w.H2 or \
+            tuple(ts["fc_out"][0].shape) != (1, w.H3):
+        raise RuntimeError("MLP weight shapes do not chain")
+    for i, c in enumerate(vox_C):
+        w.vox_C[i] = int(c)
+    w.img_C = int(img_C)
+    need = lib.list_packed_mlp_bytes(C.byref(w))
+    if need == 0:
+        raise RuntimeError("list_packed_mlp_bytes failed: "
+                           + lib.list_last_error().decode("utf-8", "replace"))
+    dev = ts["fc_0"][0].device
+    packed = torch.empty((need,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib.list_prep_mlp_weights(C.byref(w), packed.data_ptr(), need, _stream()),
+               "list_prep_mlp_weights")
+    # temporaries made by .contiguous() are released stream-ordered by the caching allocator, and
+    # every kernel above was enqueued on the same (current) stream: no synchronisation needed
+    return PackedMlp(packed, w.F, w.H1, w.H2, w.H3, vox_C, img_C)
+
+
+_workspaces = {}
+
+
+def _workspace(device, nbytes):
+    """One grow-only workspace per (device, stream, thread): re-entrant under DataParallel threads."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, threading.get_ident())
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = None
+        _workspaces.pop(key, None)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def release_workspaces():
+    _workspaces.clear()
+
+
+def _fill_query_args(query, perm, scale, vox, packed, precision, trans_mat=None, img=None,
+                     percep_feat=None, clamp_hi=136.0):
+    lib = load()
+    _f32_cuda(query, "query")
+    if query.dim() != 3 or query.shape[2] != 3:
+        raise RuntimeError("query must be [B,N,3]")
+    B, N, _ = query.shape
+    a = ListQueryArgs()
+    a.B, a.N = B, N
+    a.query = query.data_ptr()
+    a.q_sb, a.q_sn, a.q_sc = query.stride()
+    for i in range(3):
+        a.perm[i] = int(perm[i])
+    a.scale = float(scale)
+    keep = [query]
+    if percep_feat is not None:
+        _f32_cuda(percep_feat, "percep_feat")
+        if percep_feat.dim() != 3 or percep_feat.shape[0] != B or percep_feat.shape[2] != N:
+            raise RuntimeError("percep_feat must be [B,C,N]")
+        a.percep_feat = percep_feat.data_ptr()
+        a.pf_sb, a.pf_sc, a.pf_sn = percep_feat.stride()
+        a.img_C = percep_feat.shape[1]
+        keep.append(percep_feat)
+    else:
+        tm = _f32_cuda(trans_mat, "trans_mat").reshape(B, 4, 3).contiguous()
+        a.trans_mat = tm.data_ptr()
+        a.img_map = img.data.data_ptr()
+        a.map_size, a.img_C = img.map_size, img.channels
+        a.clamp_hi = float(clamp_hi)
+        keep += [tm, img]
+    for i in range(N_VOX_LEVELS):
+        a.vox[i] = vox.levels[i]
+    a.packed_mlp = packed.data.data_ptr()
+    a.F, a.H1, a.H2, a.H3 = packed.F, packed.H1, packed.H2, packed.H3
+    a.precision = PRECISIONS[precision] if isinstance(precision, str) else int(precision)
+    nbytes = lib.list_query_workspace_bytes(B * N, a.F, a.H1, a.H2, a.H3)
+    ws = _workspace(query.device, nbytes)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    keep.append(ws)
+    return a, keep
+
+
+def sdf_query(query, trans_mat, img, vox, packed, perm=(2, 1, 0), scale=2.0, precision="bf16x3",
+              percep_feat=None, out=None, stage_events=None):
+    """The fused hot path, network/models.py:91-97 -> sdf [B,N] (float32).
+
+    stage_events: optional ctypes array (c_void_p * N_STAGES) of hipEvent_t handles."""
+    lib = load()
+    a, keep = _fill_query_args(query, perm, scale, vox, packed, precision, trans_mat, img, percep_feat)
+    if stage_events is not None:
+        a.stage_events = C.cast(stage_events, C.POINTER(C.c_void_p))
+    B, N = a.B, a.N
+    sdf = out if out is not None else torch.empty((B, N), dtype=torch.float32, device=query.device)
+    if not sdf.is_contiguous() or sdf.dtype != torch.float32 or tuple(sdf.shape) != (B, N):
+        raise RuntimeError("out must be a contiguous float32 [B,N] tensor")
+    a.sdf = sdf.data_ptr()
+    with torch.cuda.device(query.device):
+        _check(lib.list_sdf_query_fwd(C.byref(a), _stream()), "list_sdf_query_fwd")
+    return sdf
+
+
+def gather_features(query, trans_mat, img, vox, packed, perm=(2, 1, 0), scale=2.0,
+                    percep_feat=None):
+    """Diagnostic: the concatenated feature tensor of network/modules.py:275, [B,F,N]."""
+    lib = load()
+    a, keep = _fill_query_args(query, perm, scale, vox, packed, "bf16x3", trans_mat, img, percep_feat)
+    out = torch.zeros((a.B, a.F, a.N), dtype=torch.float32, device=query.device)
+    with torch.cuda.device(query.device):
+        _check(lib.list_gather_features_fwd(C.byref(a), out.data_ptr(), _stream()),
+               "list_gather_features_fwd")
+    return out
+
+
+def percep_pool(pc, trans_mat, img, clamp_hi=136.0):
+    """PerceptualPooling.forward on a prepared map -> [B,Ct,1,N] (network/modules.py:37-53)."""
+    lib = load()
+    _f32_cuda(pc, "pc")
+    B, N, _ = pc.shape
+    tm = _f32_cuda(trans_mat, "trans_mat").reshape(B, 4, 3).contiguous()
+    out = torch.empty((B, img.channels, 1, N), dtype=torch.float32, device=pc.device)
+    a = ListPoolArgs()
+    a.B, a.N = B, N
+    a.pc = pc.data_ptr()
+    a.p_sb, a.p_sn, a.p_sc = pc.stride()
+    a.trans_mat = tm.data_ptr()
+    a.img_map, a.map_size, a.img_C = img.data.data_ptr(), img.map_size, img.channels
+    a.clamp_hi = float(clamp_hi)
+    a.out = out.data_ptr()
+    with torch.cuda.device(pc.device):
+        _check(lib.list_percep_pool_fwd(C.byref(a), _stream()), "list_percep_pool_fwd")
+    return out
+
+
+def split_bf16(x):
+    """float32 -> (hi, lo) bf16 planes as int16 tensors."""
+    lib = load()
+    x = _f32_cuda(x, "x").contiguous()
+    hi = torch.empty(x.shape, dtype=torch.int16, device=x.device)
+    lo = torch.empty(x.shape, dtype=torch.int16, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib.list_split_bf16(x.data_ptr(), hi.data_ptr(), lo.data_ptr(), x.numel(), _stream()),
+               "list_split_bf16")
+    return hi, lo
+
+
+def gemm_nt(a, w, bias=None, relu=False, precision="bf16x3"):
+    """Diagnostic: out[M,N] = act(a[M,K] @ w[N,K]^T + bias) through the MLP's MFMA kernel."""
+    lib = load()
+    M, K = a.shape
+    N = w.shape[0]
+    a_hi, a_lo = split_bf16(a)
+    w_hi, w_lo = split_bf16(w)
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    b = _f32_cuda(bias, "bias").contiguous() if bias is not None else None
+    with torch.cuda.device(a.device):
+        _check(lib.list_gemm_nt(a_hi.data_ptr(), a_lo.data_ptr(), w_hi.data_ptr(), w_lo.data_ptr(),
+                                b.data_ptr() if b is not None else None, out.data_ptr(), M, N, K,
+                                int(relu), PRECISIONS[precision], _stream()), "list_gemm_nt")
+    return out

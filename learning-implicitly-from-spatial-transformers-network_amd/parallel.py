@@ -1,0 +1,70 @@
+"""Sharding of the (batch x query-point) axis: one process per GPU, torch.distributed.
+
+The reference's only multi-GPU mechanism is single-process nn.DataParallel (train.py:126), which
+scatters the batch, re-broadcasts 105 M parameters every forward and gathers every output on GPU 0.
+Here every query point is independent given its image's maps, so:
+
+  * training / batched queries : the BATCH axis is partitioned (B_global = world * B_local);
+  * inference on one image     : the QUERY axis is partitioned (contiguous slices of the grid);
+  * the only data-path exchange is ONE all-gather of the fp32 SDF shards ([B_local,N] per rank,
+    640 KB at B_local=8, N=20k) so that every rank can evaluate the reference's full-batch SDFLoss
+    (network/losses.py:21-22).  Backend "nccl" is RCCL over xGMI on ROCm; the CPU tests use gloo.
+"""
+import torch
+import torch.distributed as dist
+
+
+def world_info(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def shard_range(total, rank, world):
+    """Contiguous, balanced [begin, end) of `total` items for `rank` (first `total % world` ranks
+    get one extra item)."""
+    base, extra = divmod(total, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def gather_sdf_shards(sdf_local, out=None, group=None):
+    """All-gather equally-shaped SDF shards along dim 0 -> [world*B_local, N]."""
+    rank, world = world_info(group)
+    if world == 1:
+        if out is None:
+            return sdf_local
+        out.copy_(sdf_local)
+        return out
+    sdf_local = sdf_local.contiguous()
+    if out is None:
+        out = torch.empty((world * sdf_local.shape[0],) + tuple(sdf_local.shape[1:]),
+                          dtype=sdf_local.dtype, device=sdf_local.device)
+    dist.all_gather_into_tensor(out, sdf_local, group=group)
+    return out
+
+
+def gather_ragged_points(values_local, total, group=None):
+    """All-gather of ragged 1-D shards produced with shard_range (query-axis partition of one
+    image's grid): pads to the largest shard, gathers, and trims -> [total]."""
+    rank, world = world_info(group)
+    if world == 1:
+        return values_local
+    longest = (total + world - 1) // world
+    pad = torch.zeros((longest,), dtype=values_local.dtype, device=values_local.device)
+    pad[: values_local.numel()] = values_local.reshape(-1)
+    buf = torch.empty((world * longest,), dtype=values_local.dtype, device=values_local.device)
+    dist.all_gather_into_tensor(buf, pad, group=group)
+    parts = []
+    for r in range(world):
+        b, e = shard_range(total, r, world)
+        parts.append(buf[r * longest: r * longest + (e - b)])
+    return torch.cat(parts)
+
+
+def full_batch_sdf_loss(sdf_local, targets_local, sdf_scale=1.0, group=None):
+    """The reference's SDFLoss value (network/losses.py:21-22: mean over the batch of the
+    per-image sum of squared errors) evaluated over the GLOBAL batch on every rank."""
+    pred = gather_sdf_shards(sdf_local, group=group)
+    tgt = gather_sdf_shards(targets_local, group=group)
+    return torch.mean(((tgt * sdf_scale - pred) ** 2).sum(-1))

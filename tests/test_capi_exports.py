@@ -1,0 +1,51 @@
+"""CPU: the C-ABI library loads and exports every symbol include/list_hip.h declares
+(no compute call is made here: there is no GPU in the authoring container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "list_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(list_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_expected_entry_points():
+    names = _declared()
+    for must in ("list_sdf_query_fwd", "list_prep_img_maps", "list_prep_vox_maps",
+                 "list_prep_mlp_weights", "list_percep_pool_fwd", "list_query_workspace_bytes",
+                 "list_last_error"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    from list_amd import hip
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    for name in _declared():
+        assert hasattr(lib, name), f"{name} declared in list_hip.h but not exported"
+    assert set(hip.EXPORTS) == set(_declared())
+
+
+def test_abi_version_and_error_string_without_gpu():
+    from list_amd import hip
+    lib = hip.load()
+    assert lib.list_abi_version() == 1
+    # argument validation happens before any HIP call: a NULL args struct is rejected cleanly
+    assert lib.list_sdf_query_fwd(None, None) == -1
+    assert b"NULL" in lib.list_last_error()
+    assert lib.list_query_workspace_bytes(160000, 3610, 512, 256, 256) > 2 * 160000 * 3648 * 2
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from list_amd import hip
+    monkeypatch.setattr(hip, "_lib", None)
+    monkeypatch.setattr(hip, "LIB_PATH", "/nonexistent/liblist_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
+        hip.load()
