@@ -30,7 +30,9 @@ def build(force=False, verbose=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build liblist_hip.so")
-    cmd = [hipcc, "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared",
+    # -ffp-contract=off: coordinates and interpolation weights must round exactly like the
+    # reference's CPU ops (an fma of "scale*x - floor" skips a rounding); fmaf is explicit where wanted
+    cmd = [hipcc, "-O3", "-std=c++17", "-ffp-contract=off", f"--offload-arch={ARCH}", "-fPIC", "-shared",
            "-I", INCLUDE, "-I", CSRC] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

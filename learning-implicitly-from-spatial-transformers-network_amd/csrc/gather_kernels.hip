@@ -43,7 +43,7 @@ __device__ __forceinline__ Axis axis_setup(float c, int size) {
 }
 
 __device__ __forceinline__ float4 fma4(const float4& v, float w, const float4& a) {
-  return make_float4(v.x * w + a.x, v.y * w + a.y, v.z * w + a.z, v.w * w + a.w);
+  return make_float4(fmaf(v.x, w, a.x), fmaf(v.y, w, a.y), fmaf(v.z, w, a.z), fmaf(v.w, w, a.w));
 }
 
 // One trilinear sample of 4 channels.  base points at (image, channel quad).
@@ -226,13 +226,13 @@ __device__ __forceinline__ float trilinear1(const float* __restrict__ base, int 
   const int o = (az.i0 * H + ay.i0) * W + ax.i0;
   const int sx = ax.has1 ? 1 : 0, sy = ay.has1 ? W : 0, sz = az.has1 ? H * W : 0;
   float acc = base[o] * (ax.w0 * ay.w0 * az.w0);
-  acc = base[o + sx] * (ax.w1 * ay.w0 * az.w0) + acc;
-  acc = base[o + sy] * (ax.w0 * ay.w1 * az.w0) + acc;
-  acc = base[o + sy + sx] * (ax.w1 * ay.w1 * az.w0) + acc;
-  acc = base[o + sz] * (ax.w0 * ay.w0 * az.w1) + acc;
-  acc = base[o + sz + sx] * (ax.w1 * ay.w0 * az.w1) + acc;
-  acc = base[o + sz + sy] * (ax.w0 * ay.w1 * az.w1) + acc;
-  acc = base[o + sz + sy + sx] * (ax.w1 * ay.w1 * az.w1) + acc;
+  acc = fmaf(base[o + sx], ax.w1 * ay.w0 * az.w0, acc);
+  acc = fmaf(base[o + sy], ax.w0 * ay.w1 * az.w0, acc);
+  acc = fmaf(base[o + sy + sx], ax.w1 * ay.w1 * az.w0, acc);
+  acc = fmaf(base[o + sz], ax.w0 * ay.w0 * az.w1, acc);
+  acc = fmaf(base[o + sz + sx], ax.w1 * ay.w0 * az.w1, acc);
+  acc = fmaf(base[o + sz + sy], ax.w0 * ay.w1 * az.w1, acc);
+  acc = fmaf(base[o + sz + sy + sx], ax.w1 * ay.w1 * az.w1, acc);
   return acc;
 }
 
