@@ -1,0 +1,130 @@
+"""Executors with the reference's interface (network/executors.py:26-268): `train(batch, calc_loss)`,
+`test(batch, eval_pred)`, `calc_loss`, `eval`, `save`.  The class for a model is found by name:
+network.models.X <-> network.executors.X (train.py of the reference, line 242)."""
+import numpy as np
+import torch
+
+from .. import parallel, utils
+from . import losses as L
+
+
+def _unwrap(model):
+    return model.module if hasattr(model, "module") else model
+
+
+def chamfer_distance(x, y):
+    """Symmetric mean squared nearest-neighbour distance between point sets [B,N,3], [B,M,3]
+    (what pytorch3d.loss.chamfer_distance returns with default arguments)."""
+    d = torch.cdist(x, y) ** 2
+    return d.min(2)[0].mean(1).mean() + d.min(1)[0].mean(1).mean(), None
+
+
+class CoarseNet:
+    def __init__(self, config, model):
+        self.loss_fn = chamfer_distance
+        self.use_cuda = config.cuda
+        self.model = model
+        self.coarse_points = config.coarse_point_density
+
+    def calc_loss(self, pred, gt):
+        return self.loss_fn(pred, gt)[0] * 1000
+
+    def _device(self):
+        return next(self.model.parameters()).device
+
+    def train(self, batch, calc_loss=True):
+        img, gt = batch["rgb_image"].to(self._device()), batch["pc"].to(self._device())
+        pred = self.model(img)
+        return pred, {"chamfer_loss": self.calc_loss(pred, gt) if calc_loss else []}
+
+    def test(self, batch, eval_pred=False):
+        img, gt = batch
+        pred = self.model(img.to(self._device())).detach().cpu()
+        return pred, (self.eval(pred, gt) if eval_pred else {})
+
+    def eval(self, pred, gt):
+        if pred.shape[0] > 1:
+            print("Evaluation of multiple predictions (batch_size > 1) is not allowed.")
+            return {}
+        return {"chamfer_l2": float(chamfer_distance(pred, gt)[0])}
+
+    def save(self, batch, pred, fname):
+        if pred.shape[0] == 1:
+            utils.write_obj(fname + "_pred.obj", pred.squeeze(0).numpy(), [])
+
+
+class LIST:
+    def __init__(self, config, model):
+        print(self.__class__.__name__, "executor")
+        self.model = model
+        self.use_cuda = config.cuda
+        self.device = getattr(config, "device", None)
+        self.test_pointnum = config.test_pointnum
+        self.sdf_scale = config.sdf_scale
+        self.max_dist = config.sdf_max_dist
+        self.query_res = getattr(config, "mcube_znum", None) or config.vox_res
+        self.bb_min, self.bb_max, self.vox_res = config.bb_min, config.bb_max, config.vox_res
+        self.loss_sdf = L.SDFLoss(self.sdf_scale)
+
+    def _device(self):
+        return self.device or next(self.model.parameters()).device
+
+    def create_grid(self):
+        return utils.create_grid_points_from_bounds(self.bb_min, self.bb_max, self.vox_res)
+
+    def calc_loss(self, pred, gt):
+        occ, sdf_pred = pred
+        occ_gt, sdf_gt = gt
+        w = 0.9                                     # weighted BCE on the occupancy head (executors.py:138-141)
+        occ_loss = 1000 * (-w * torch.mean(occ_gt * torch.log(occ + 1e-8))
+                           - (1 - w) * torch.mean((1 - occ_gt) * torch.log(1 - occ + 1e-8)))
+        loss = {"occ_loss": occ_loss}
+        loss.update(self.loss_sdf(sdf_pred, sdf_gt))
+        return loss
+
+    def train(self, batch, calc_loss=True):
+        dev = self._device()
+        img, points = batch["rgb_image"].to(dev), batch["points"].to(dev)
+        sdf_gt, occ_gt = batch["values"].to(dev), batch["occ"].to(dev)
+        transmat = batch["transmat"].to(dev) if "transmat" in batch else None
+        pred = self.model(img, points, transmat)
+        return pred, (self.calc_loss(pred, [occ_gt, sdf_gt]) if calc_loss else [])
+
+    @torch.no_grad()
+    def predict_grid(self, img, transmat=None, res=None, shard=True):
+        """SDF on the regular res^3 grid over [-0.5,0.5]^3 (reference executors.py:191-231) ->
+        float32 tensor [res,res,res] on the device, already divided by sdf_scale.
+
+        The grid is generated on the device chunk by chunk (no host->device point copies, no
+        per-chunk .cpu()); with torch.distributed initialised and shard=True the query axis is split
+        over the ranks and all-gathered."""
+        net = _unwrap(self.model)
+        dev = img.device
+        res = res or self.query_res
+        feat_l2, vox_feat, transmat, _, occ = net.encode(img, transmat)
+        total = res ** 3
+        rank, world = parallel.world_info() if shard else (0, 1)
+        begin, end = parallel.shard_range(total, rank, world)
+        out = torch.empty((end - begin,), dtype=torch.float32, device=dev)
+        for s in range(begin, end, self.test_pointnum):
+            e = min(s + self.test_pointnum, end)
+            pts = utils.grid_points_on_device(-0.5, 0.5, res, dev, s, e).unsqueeze(0)
+            out[s - begin:e - begin] = net.query_sdf(pts, feat_l2, vox_feat, transmat)[0]
+        if world > 1:
+            out = parallel.gather_ragged_points(out, total)
+        return (out / self.sdf_scale).view(res, res, res), occ, vox_feat
+
+    def test(self, batch, eval_pred=False):
+        img = batch["rgb_image"].to(self._device())
+        transmat = batch["transmat"].to(self._device()) if "transmat" in batch else None
+        volume, occ, vox_feat = self.predict_grid(img, transmat)
+        pred_mesh = utils.generate_mesh(volume.cpu().numpy(), -0.5, 0.5, as_trimesh_obj=True)
+        score = self.eval(pred_mesh, batch.get("gt_mesh")) if eval_pred else {}
+        return [pred_mesh, occ, vox_feat[0].squeeze(1)], score
+
+    def eval(self, pred, gt):
+        raise RuntimeError("mesh evaluation (evaluation/eval_util.py of the reference) is outside the "
+                           "scope of the query path; export the mesh and evaluate offline")
+
+    def save(self, batch, pred, fname):
+        pred[0].export(fname + "_pred.obj")

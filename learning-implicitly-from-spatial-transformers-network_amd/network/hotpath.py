@@ -1,0 +1,139 @@
+"""Dispatch of the SDF query hot path (reference network/models.py:91-97) to the HIP library.
+
+Forward: always liblist_hip.so (..hip).  There is no CPU or PyTorch forward fallback: tensors that
+are not on a HIP device raise.  Backward ("next"): until the HIP backward kernels
+exist, gradients are obtained by re-evaluating the same mathematics with differentiable torch ops ON
+THE GPU inside a custom autograd.Function (`_recompute_with_torch_ops`); the forward values that the
+caller sees always come from the HIP kernels.
+"""
+import torch
+import torch.nn.functional as F
+
+from .. import hip
+
+N_IMG, N_VOX = hip.N_IMG_LEVELS, hip.N_VOX_LEVELS
+MLP_KEYS = ("fc_0.weight", "fc_0.bias", "fc_1.weight", "fc_1.bias", "fc_2.weight", "fc_2.bias",
+            "fc_out.weight", "fc_out.bias")
+_DISPLACEMENT = 0.0722        # network/modules.py:205
+
+
+def require_hip(t, what):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise RuntimeError(
+            f"{what}: the LIST SDF query path runs only on a HIP device through liblist_hip.so "
+            f"(got a {t.device if isinstance(t, torch.Tensor) else type(t).__name__} tensor); "
+            "there is no CPU/PyTorch fallback")
+
+
+def _f32(t):
+    return t if t.dtype == torch.float32 else t.float()
+
+
+class _Cache:
+    """Remembers the last prepared object for a tuple of source tensors (same storage, same
+    version counter => same content), e.g. across the chunk loop of executors.LIST.test."""
+
+    def __init__(self):
+        self.key, self.value = None, None
+
+    def get(self, tensors, make):
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.device.index)
+                    for t in tensors)
+        if key != self.key:
+            self.value = make()
+            self.key = key
+        return self.value
+
+
+def stencil_offsets(device, dtype=torch.float32):
+    d = _DISPLACEMENT
+    return torch.tensor([[0, 0, 0], [-d, 0, 0], [d, 0, 0], [0, -d, 0], [0, d, 0], [0, 0, -d], [0, 0, d]],
+                        dtype=dtype, device=device)
+
+
+def _recompute_with_torch_ops(pts, trans_mat, img_maps, vox_maps, mlp, map_size, percep=None):
+    """Differentiable re-evaluation on the device (used for gradients only)."""
+    B, N, _ = pts.shape
+    if percep is None:
+        ones = pts.new_ones(B, N, 1)
+        cam = torch.matmul(torch.cat((pts, ones), -1), trans_mat)
+        uv = (cam[..., :2] / (cam[..., 2:] + 1e-8)).clamp(0.0, 136.0)
+        half = (map_size - 1) / 2.0
+        grid2 = ((uv - half) / half).unsqueeze(1)
+        pooled = [F.grid_sample(F.interpolate(m, size=map_size, mode="bilinear", align_corners=True),
+                                grid2, align_corners=True) for m in img_maps]
+        percep = torch.cat(pooled, 1).squeeze(2)
+    grid3 = pts[:, None, None, :, :] + stencil_offsets(pts.device)[None, None, :, None, :]
+    vf = torch.cat([F.grid_sample(f, grid3, padding_mode="border", align_corners=True)
+                    for f in vox_maps], 1)
+    feats = torch.cat((vf.reshape(B, vf.shape[1] * 7, N), percep, pts.transpose(1, 2)), 1)
+    h = feats
+    for i in range(3):
+        h = F.relu(F.conv1d(h, mlp[2 * i].reshape(mlp[2 * i].shape[0], -1, 1), mlp[2 * i + 1]))
+    return F.conv1d(h, mlp[6].reshape(1, -1, 1), mlp[7]).squeeze(1)
+
+
+class _SdfQueryFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, runner, pts_args, query, trans_mat, percep, *tensors):
+        ctx.runner, ctx.pts_args = runner, pts_args
+        ctx.has_percep = percep is not None
+        ctx.save_for_backward(query, trans_mat, percep, *tensors)
+        return runner()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        query, trans_mat, percep, *tensors = ctx.saved_tensors
+        perm, scale, map_size = ctx.pts_args
+        img_maps, vox_maps, mlp = tensors[:N_IMG], tensors[N_IMG:N_IMG + N_VOX], tensors[N_IMG + N_VOX:]
+        with torch.enable_grad():
+            leaves = [t.detach().requires_grad_(t.requires_grad) if t is not None else None
+                      for t in (trans_mat, percep, *tensors)]
+            tm, pf = leaves[0], leaves[1]
+            rest = leaves[2:]
+            pts = query.detach()[:, :, list(perm)] * scale
+            sdf = _recompute_with_torch_ops(pts, tm, rest[:N_IMG], rest[N_IMG:N_IMG + N_VOX],
+                                            rest[N_IMG + N_VOX:], map_size, pf)
+            wanted = [t for t in leaves if t is not None and t.requires_grad]
+            grads = torch.autograd.grad(sdf, wanted, grad_out, allow_unused=True) if wanted else []
+        it = iter(grads)
+        out = [next(it) if (t is not None and t.requires_grad) else None for t in leaves]
+        return (None, None, None, *out)
+
+
+def sdf_query(query, trans_mat, img_maps, vox_maps, mlp_params, *, perm=(2, 1, 0), scale=2.0,
+              map_size=137, precision="bf16x3", percep_feat=None, caches=None):
+    """sdf [B,N] for raw queries; mlp_params: dict with the reference's fc_* keys."""
+    require_hip(query, "query")
+    caches = caches or {}
+    query = _f32(query)
+    vox_maps = [_f32(v) for v in vox_maps]
+    mlp = [mlp_params[k] for k in MLP_KEYS]
+    if percep_feat is None:
+        img_maps = [_f32(m) for m in img_maps]
+        img = caches.setdefault("img", _Cache()).get(
+            img_maps, lambda: hip.prep_img_maps([m.detach() for m in img_maps], map_size))
+    else:
+        img_maps, img = [], None
+    vox = caches.setdefault("vox", _Cache()).get(
+        vox_maps, lambda: hip.prep_vox_maps([v.detach() for v in vox_maps]))
+    img_C = img.channels if img is not None else percep_feat.shape[1]
+    packed = caches.setdefault("mlp", _Cache()).get(
+        mlp, lambda: hip.prep_mlp_weights({k: t.detach() for k, t in zip(MLP_KEYS, mlp)},
+                                          vox.channels, img_C))
+
+    def run():
+        return hip.sdf_query(query.detach(), trans_mat.detach() if trans_mat is not None else None,
+                             img, vox, packed, perm=perm, scale=scale, precision=precision,
+                             percep_feat=percep_feat.detach() if percep_feat is not None else None)
+
+    diff = [t for t in (trans_mat, percep_feat, *img_maps, *vox_maps, *mlp)
+            if t is not None and t.requires_grad]
+    if torch.is_grad_enabled() and diff:
+        if percep_feat is None:
+            tensors = (*img_maps, *vox_maps, *mlp)
+        else:   # keep the positional layout expected by backward
+            tensors = (*([vox_maps[0].new_zeros(1)] * N_IMG), *vox_maps, *mlp)
+        return _SdfQueryFn.apply(run, (tuple(perm), float(scale), map_size), query, trans_mat,
+                                 percep_feat, *tensors)
+    return run()

@@ -101,6 +101,57 @@ def main():
         displacements=dec.displacments.numpy(),
     )
     print("aux written")
+    model_goldens(torch)
+
+
+def _harness_resnet18(pretrained=False, **kw):
+    """The reference wraps torchvision.models.resnet18 (modules.py:1030); torchvision is absent, so
+    the stub hands it this package's own ResNet-18 definition (same attribute names)."""
+    from list_amd.network.resnet import resnet18
+    return resnet18()
+
+
+def model_goldens(torch):
+    """Whole-model goldens: state-dict names/shapes of the reference's LIST and CoarseNet, a CoarseNet
+    forward (plumbing config #1) and a LIST forward, all with parameters from oracle/fill.py."""
+    import json
+    import types as _t
+    from . import fill, synth
+    sys.modules["torchvision.models"].resnet18 = _harness_resnet18
+    sys.modules["torchvision"].models.resnet18 = _harness_resnet18
+    import network.models as RM                                   # reference
+    import utils as RU                                            # reference
+    RU.get_kdtree_orig = RU.get_kdtree
+    cfg = _t.SimpleNamespace(vox_res=32, im_enc_layers=[1, 1, 1, 1, 16, 32, 64, 128, 128],
+                             train_batch_size=2, point_feat=[128, 128, 256, 256, 256, 128, 128, 3],
+                             point_degree=[2, 2, 2, 2, 2, 2, 64], bb_min=-0.5, bb_max=0.5)
+    orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        ref_list = RM.LIST(cfg)
+        ref_coarse = RM.CoarseNet(cfg)
+    finally:
+        torch.Tensor.cuda = orig
+    keys = {"LIST": {k: list(v.shape) for k, v in ref_list.state_dict().items()},
+            "CoarseNet": {k: list(v.shape) for k, v in ref_coarse.state_dict().items()}}
+    with open(os.path.join(OUT, "state_dict_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0, sort_keys=True)
+
+    fill.fill_state(ref_coarse, seed=1).eval()
+    img = torch.from_numpy(synth.uniform(77, (2, 3, 128, 128)))
+    with torch.no_grad():
+        pc = ref_coarse(img)
+    fill.fill_state(ref_list, seed=2).eval()
+    img2 = torch.from_numpy(synth.uniform(78, (2, 3, 64, 64)))
+    q = torch.from_numpy(synth.make_query(79, 2, 100))
+    with torch.no_grad():
+        occ_feat, sdf = ref_list(img2, q)
+        tm = torch.from_numpy(synth.make_trans_mat(80, 2))
+        _, sdf_tm = ref_list(img2, q, tm)
+    np.savez_compressed(os.path.join(OUT, "models.npz"), coarse_pc=pc.numpy(), list_sdf=sdf.numpy(),
+                        list_sdf_given_transmat=sdf_tm.numpy(), list_vox0=occ_feat.numpy()[:, :, ::4, ::4, ::4])
+    print("models: coarse", tuple(pc.shape), float(pc.abs().max()), "list sdf", tuple(sdf.shape),
+          float(sdf.abs().max()), float(sdf_tm.abs().max()))
 
 
 if __name__ == "__main__":

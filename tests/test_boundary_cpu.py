@@ -1,0 +1,118 @@
+"""CPU: the nn.Module / entry-point mirror of the reference API (names, state-dict keys, host logic,
+config #1 plumbing = CoarseNet on CPU) against goldens produced by the reference's own models."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fill, synth
+from list_amd import arguments, utils
+
+
+@pytest.fixture(scope="module")
+def cfg():
+    return arguments.default_config(vox_res=32, train_batch_size=2, cuda=False)
+
+
+def test_get_class_resolves_reference_names():
+    assert utils.get_class("network.models.LIST").__name__ == "LIST"
+    assert utils.get_class("network.executors.LIST").__name__ == "LIST"
+    assert utils.get_class("network.models.CoarseNet").__name__ == "CoarseNet"
+    assert utils.get_class("datasets.Datasets.IM2SDF").__name__ == "SyntheticIM2SDF"
+    with pytest.raises(ImportError):
+        utils.get_class("network.models.Nope")
+
+
+def test_state_dict_names_and_shapes_match_reference(cfg, golden_dir):
+    ref = json.load(open(os.path.join(golden_dir, "state_dict_keys.json")))
+    for name in ("LIST", "CoarseNet"):
+        mine = {k: list(v.shape) for k, v in utils.get_class(f"network.models.{name}")(cfg).state_dict().items()}
+        assert mine == ref[name], set(mine) ^ set(ref[name])
+
+
+def test_coarsenet_cpu_plumbing_matches_reference(cfg, golden_dir):
+    """BASELINE config #1: CoarseNet, B=2, 4096 coarse points, 128^2 images, PyTorch CPU."""
+    g = np.load(os.path.join(golden_dir, "models.npz"))
+    net = fill.fill_state(utils.get_class("network.models.CoarseNet")(cfg), seed=1).eval()
+    with torch.no_grad():
+        pc = net(torch.from_numpy(synth.uniform(77, (2, 3, 128, 128))))
+    assert pc.shape == (2, 4096, 3)
+    np.testing.assert_allclose(pc.numpy(), g["coarse_pc"], rtol=0, atol=2e-6)
+
+
+def test_list_encode_and_device_occupancy_match_reference(cfg, golden_dir):
+    """Per-image stage on CPU: encoders, camera MLP and the on-device occupancy rounding (which
+    replaces the reference's host KD-tree) reproduce the reference's first voxel map."""
+    g = np.load(os.path.join(golden_dir, "models.npz"))
+    net = fill.fill_state(utils.get_class("network.models.LIST")(cfg), seed=2).eval()
+    with torch.no_grad():
+        feat_l2, vox_feat, tm, pc, occ = net.encode(torch.from_numpy(synth.uniform(78, (2, 3, 64, 64))))
+    assert [tuple(f.shape[1:]) for f in vox_feat] == [(1, 32, 32, 32), (16, 32, 32, 32), (32, 16, 16, 16),
+                                                     (64, 8, 8, 8), (128, 4, 4, 4), (128, 2, 2, 2)]
+    assert tm.shape == (2, 4, 3) and len(feat_l2) == 5
+    np.testing.assert_allclose(vox_feat[0].numpy()[:, :, ::4, ::4, ::4], g["list_vox0"], rtol=0, atol=1e-5)
+
+
+def test_hot_path_has_no_cpu_fallback(cfg):
+    net = utils.get_class("network.models.LIST")(cfg).eval()
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
+        net(torch.rand(2, 3, 64, 64), torch.rand(2, 10, 3) - 0.5)
+    from list_amd.network import modules as M
+    with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
+        M.PerceptualPooling()([torch.rand(1, 4, 8, 8)] * 5, torch.rand(1, 3, 3), torch.rand(1, 4, 3))
+    assert "oracle" not in open(M.__file__).read()
+
+
+def test_sdf_loss_and_grid_match_reference(golden_dir):
+    a = np.load(os.path.join(golden_dir, "aux.npz"))
+    from list_amd.network.losses import SDFLoss
+    out = SDFLoss(2.0)(torch.from_numpy(a["loss_outputs"]), torch.from_numpy(a["loss_targets"]))
+    for k, v in out.items():
+        np.testing.assert_allclose(v.numpy(), a["loss_" + k], rtol=2e-6)
+    np.testing.assert_array_equal(utils.create_grid_points_from_bounds(-0.5, 0.5, 8), a["grid8"])
+    for res in (8, 31, 128):
+        host = torch.tensor(utils.create_grid_points_from_bounds(-0.5, 0.5, res)).float()
+        b, e = res ** 3 // 3, res ** 3 // 3 + 4097
+        dev = utils.grid_points_on_device(-0.5, 0.5, res, "cpu", b, min(e, res ** 3))
+        assert torch.equal(dev, host[b:e])
+    from list_amd.network import hotpath
+    np.testing.assert_array_equal(hotpath.stencil_offsets("cpu").numpy(), a["displacements"])
+
+
+def test_checkpoint_format_roundtrip(cfg, tmp_path):
+    from list_amd.train import _Module
+    net = _Module(utils.get_class("network.models.CoarseNet")(cfg))
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    fn = str(tmp_path / "best_model_train.pt.tar")
+    utils.save_checkpoint(4, net, opt, 0.25, fn)
+    ck = torch.load(fn, map_location="cpu")
+    assert set(ck) == {"epoch", "state_dict", "optimizer", "bestloss"} and ck["epoch"] == 5
+    assert not any(k.startswith("module.") for k in ck["state_dict"])
+    epoch, _, _, best = utils.load_checkpoint(fn, net, opt)
+    assert (epoch, best) == (5, 0.25)
+
+
+def test_synthetic_datasets_have_reference_keys(cfg):
+    cfg2 = arguments.default_config(vox_res=16, img_res=32, sample_point_density=200, cuda=False)
+    item = utils.get_class("datasets.Datasets.SyntheticIM2SDF")(cfg2, "train")[0]
+    assert set(item) == {"rgb_image", "points", "values", "occ"}
+    assert item["rgb_image"].shape == (3, 32, 32) and item["points"].shape == (200, 3)
+    assert item["values"].shape == (200,) and item["occ"].shape == (16, 16, 16)
+    assert float(item["points"].abs().max()) <= 0.5
+    pf = utils.get_class("datasets.Datasets.SyntheticIM2PointFarthest")(cfg2, "train")[1]
+    assert pf["pc"].shape == (5000, 3)
+
+
+def test_train_entry_point_coarsenet_cpu_one_step(tmp_path):
+    """train.py plumbing on CPU (config #1): one optimisation step with the synthetic loader."""
+    from list_amd import train as T
+    cfg = arguments.default_config(model="network.models.CoarseNet",
+                                   dataset="datasets.Datasets.SyntheticIM2PointFarthest", cuda=False,
+                                   img_res=128, train_batch_size=2, synthetic_len=2, max_steps=1, epochs=1,
+                                   output_dir=str(tmp_path) + "/", exp_name="t", load_pretrain=False)
+    utils.ensure_dir(cfg.checkpoint_dir)
+    loss = T.train(cfg)
+    assert np.isfinite(loss)
+    assert os.path.exists(cfg.checkpoint_dir + "best_model_train.pt.tar")

@@ -1,0 +1,127 @@
+"""GPU: the nn.Module mirror (LIST / PerceptualPooling / VoxelDecoder2 / executor / train.py) running
+the HIP path, against goldens from the reference's own LIST.forward and against torch on the device."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fill, synth, torch_ops as TO
+from list_amd import arguments, utils
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def cfg():
+    return arguments.default_config(vox_res=32, train_batch_size=2)
+
+
+@pytest.fixture(scope="module")
+def net(cfg):
+    return fill.fill_state(utils.get_class("network.models.LIST")(cfg), seed=2).eval()
+
+
+def test_list_forward_matches_reference_model(net, golden_dir):
+    g = np.load(os.path.join(golden_dir, "models.npz"))
+    img = torch.from_numpy(synth.uniform(78, (2, 3, 64, 64)))
+    q = torch.from_numpy(synth.make_query(79, 2, 100))
+    tm_given = torch.from_numpy(synth.make_trans_mat(80, 2))
+    with torch.no_grad():
+        # (a) per-image stage on the CPU (bit-comparable with the reference's CPU run), per-point stage on HIP
+        feat_l2, vox_feat, tm, _, _ = net.encode(img)
+        net_gpu_dec = net.sdf_decoder.to(DEV)
+        sdf = net.query_sdf(q.to(DEV), [f.to(DEV) for f in feat_l2], [v.to(DEV) for v in vox_feat], tm.to(DEV))
+        assert np.abs(sdf.cpu().numpy() - g["list_sdf"]).max() < 1e-4
+        sdf2 = net.query_sdf(q.to(DEV), [f.to(DEV) for f in feat_l2], [v.to(DEV) for v in vox_feat],
+                             tm_given.to(DEV))
+        assert np.abs(sdf2.cpu().numpy() - g["list_sdf_given_transmat"]).max() < 1e-4
+        # (b) everything on the GPU (MIOpen convolutions differ from the CPU's in the last bits)
+        net.to(DEV)
+        vox0, sdf3 = net(img.to(DEV), q.to(DEV))
+        assert vox0.shape == (2, 1, 32, 32, 32) and sdf3.shape == (2, 100)
+        err = np.abs(sdf3.cpu().numpy() - g["list_sdf"]).max()
+        print(f"whole-GPU LIST.forward vs reference CPU: {err:.3e}")
+        assert err < 2e-3
+    net.cpu()
+
+
+def test_module_level_calls_equal_fused(net):
+    """executors.LIST.test of the reference calls percep_pooling then sdf_decoder by attribute."""
+    net.to(DEV)
+    img = torch.from_numpy(synth.uniform(78, (2, 3, 64, 64))).to(DEV)
+    q = torch.from_numpy(synth.make_query(5, 2, 333)).to(DEV)
+    with torch.no_grad():
+        feat_l2, vox_feat, tm, _, _ = net.encode(img)
+        fused = net.query_sdf(q, feat_l2, vox_feat, tm)
+        p = q[:, :, [2, 1, 0]] * 2
+        percep = net.percep_pooling(feat_l2, p, tm)
+        assert percep.shape == (2, 1024, 1, 333)
+        two_step = net.sdf_decoder(p, vox_feat, percep.reshape(2, -1, 333))
+    # same kernels and same split of the same fp32 features -> identical
+    assert torch.equal(fused, two_step)
+    net.cpu()
+
+
+def test_gradients_flow_through_the_query(net):
+    net.to(DEV)
+    img = torch.from_numpy(synth.uniform(78, (2, 3, 64, 64))).to(DEV)
+    q = torch.from_numpy(synth.make_query(6, 2, 64)).to(DEV)
+    with torch.no_grad():
+        feat_l2, vox_feat, tm, _, _ = net.encode(img)
+    leaves = [t.clone().requires_grad_(True) for t in (tm, feat_l2[0], vox_feat[3])]
+    fl = [leaves[1]] + feat_l2[1:]
+    vf = vox_feat[:3] + [leaves[2]] + vox_feat[4:]
+    sdf = net.query_sdf(q, fl, vf, leaves[0])
+    w = torch.linspace(-1, 1, sdf.numel(), device=DEV).view_as(sdf)
+    (sdf * w).sum().backward()
+    pw = net.sdf_decoder.fc["fc_0"].weight
+    assert pw.grad is not None and torch.isfinite(pw.grad).all() and pw.grad.abs().sum() > 0
+    # independent torch evaluation on the device
+    ref_leaves = [t.detach().clone().requires_grad_(True) for t in leaves]
+    weights = {k: v.detach().clone().requires_grad_(True) for k, v in net.sdf_decoder.mlp_params().items()}
+    pts = q[:, :, [2, 1, 0]] * 2
+    percep = TO.pooled_image_features([ref_leaves[1]] + [f.detach() for f in feat_l2[1:]], pts, ref_leaves[0])
+    feats = torch.cat((TO.stencil_voxel_features(pts, [v.detach() for v in vox_feat[:3]] + [ref_leaves[2]]
+                                                 + [v.detach() for v in vox_feat[4:]]), percep,
+                       pts.transpose(1, 2)), 1)
+    ref = TO.implicit_mlp(feats, weights)
+    assert (ref - sdf).abs().max() < 1e-4
+    (ref * w).sum().backward()
+    for a, b in zip(leaves, ref_leaves):
+        assert torch.allclose(a.grad, b.grad, rtol=1e-3, atol=1e-5)
+    assert torch.allclose(pw.grad, weights["fc_0.weight"].grad, rtol=1e-3, atol=1e-5)
+    net.zero_grad()
+    net.cpu()
+
+
+def test_executor_grid_prediction(cfg, net):
+    """Inference driver (reference executors.py:191-231): chunked device-side grid == one-shot query."""
+    net.to(DEV)
+    from list_amd.train import _Module
+    cfg2 = arguments.default_config(vox_res=32, train_batch_size=2, mcube_znum=24, test_pointnum=5000)
+    cfg2.device = torch.device(DEV)
+    ex = utils.get_class("network.executors.LIST")(cfg2, _Module(net))
+    img = torch.from_numpy(synth.uniform(78, (1, 3, 64, 64))).to(DEV)
+    vol, occ, vox_feat = ex.predict_grid(img)
+    assert vol.shape == (24, 24, 24) and torch.isfinite(vol).all()
+    grid = torch.tensor(utils.create_grid_points_from_bounds(-0.5, 0.5, 24)).float().unsqueeze(0).to(DEV)
+    with torch.no_grad():
+        feat_l2, vf, tm, _, _ = net.encode(img)
+        one = net.query_sdf(grid, feat_l2, vf, tm)
+    assert torch.equal(one.view(24, 24, 24) / cfg2.sdf_scale, vol)
+    net.cpu()
+
+
+def test_train_entry_point_list_one_step_on_gpu(tmp_path):
+    from list_amd import train as T
+    cfg = arguments.default_config(model="network.models.LIST", dataset="datasets.Datasets.SyntheticIM2SDF",
+                                   img_res=64, vox_res=32, sample_point_density=512, train_batch_size=2,
+                                   synthetic_len=2, max_steps=1, epochs=1, output_dir=str(tmp_path) + "/",
+                                   exp_name="t", load_pretrain=False)
+    utils.ensure_dir(cfg.checkpoint_dir)
+    loss = T.train(cfg)
+    assert np.isfinite(loss)
+    ck = torch.load(cfg.checkpoint_dir + "best_model_train.pt.tar", map_location="cpu")
+    assert "sdf_decoder.fc.fc_0.weight" in ck["state_dict"]
