@@ -104,13 +104,18 @@ def test_executor_grid_prediction(cfg, net):
     cfg2.device = torch.device(DEV)
     ex = utils.get_class("network.executors.LIST")(cfg2, _Module(net))
     img = torch.from_numpy(synth.uniform(78, (1, 3, 64, 64))).to(DEV)
-    vol, occ, vox_feat = ex.predict_grid(img)
-    assert vol.shape == (24, 24, 24) and torch.isfinite(vol).all()
-    grid = torch.tensor(utils.create_grid_points_from_bounds(-0.5, 0.5, 24)).float().unsqueeze(0).to(DEV)
     with torch.no_grad():
-        feat_l2, vf, tm, _, _ = net.encode(img)
-        one = net.query_sdf(grid, feat_l2, vf, tm)
-    assert torch.equal(one.view(24, 24, 24) / cfg2.sdf_scale, vol)
+        enc = net.encode(img)          # MIOpen convolutions are not run-to-run deterministic (1e-7):
+    net.encode = lambda *a, **k: enc   # freeze the per-image stage so only the query path is compared
+    try:
+        vol, occ, vox_feat = ex.predict_grid(img)
+        assert vol.shape == (24, 24, 24) and torch.isfinite(vol).all()
+        grid = torch.tensor(utils.create_grid_points_from_bounds(-0.5, 0.5, 24)).float().unsqueeze(0).to(DEV)
+        with torch.no_grad():
+            one = net.query_sdf(grid, enc[0], enc[1], enc[2])
+        assert torch.equal(one.view(24, 24, 24) / cfg2.sdf_scale, vol)
+    finally:
+        del net.encode
     net.cpu()
 
 
