@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="list_im2sdf_b8_n20k_224", choices=sorted(WORKLOADS))
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-images", type=int, default=2)
     args = ap.parse_args()
@@ -137,7 +137,7 @@ def main():
         if pre: ev.record(pre[1])
         vox = hip.prep_vox_maps(inp["vox_maps"])
         if pre: ev.record(pre[2])
-        packed = hip.prep_mlp_weights(inp["weights"], vox.channels, img.channels)
+        packed = hip.prep_mlp_weights(inp["weights"], vox.channels, img.channels, args.precision)
         if pre: ev.record(pre[3])
         hip.sdf_query(inp["query"], inp["trans_mat"], img, vox, packed, precision=args.precision,
                       out=sdf, stage_events=arr)
@@ -241,11 +241,13 @@ def main():
                   else "SDF query-points/sec",
         "value": value, "unit": "query-points/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "fp16" if args.precision == "fp16" else "bf16",
+        "data": "synthetic",
         "config": {"workload": args.workload, "images_per_gpu": B, "points_per_image": N,
                    "global_points_per_step": world * P, "precision": args.precision,
-                   "mlp_arithmetic": "bf16 hi/lo split operands, 3 MFMA products per MAC, fp32 accumulate"
-                   if terms == 3 else "bf16 operands, fp32 accumulate",
+                   "mlp_arithmetic": {"bf16x3": "bf16 hi/lo split operands, 3 MFMA products per MAC, fp32 accumulate",
+                                      "fp16": "fp16 operands (saturating), 1 MFMA product per MAC, fp32 accumulate",
+                                      "bf16": "bf16 operands, 1 MFMA product per MAC, fp32 accumulate"}[args.precision],
                    "gather_arithmetic": "fp32", "inputs": "reference layout (NCHW/NCDHW fp32) resident in HBM; "
                    "layout hand-off + weight repack inside the timed step",
                    "parallelism": f"batch-sharded x{world}" + (" + RCCL all-gather of sdf" if world > 1 else "")},

@@ -42,11 +42,15 @@ enum ListStatus {
   LIST_ERR_UNSUPPORTED = -5
 };
 
-/* Arithmetic of the implicit MLP (the gathers are always fp32):
- *   BF16X3 : operands split into bf16 hi+lo, 3 MFMA products per MAC, fp32 accumulate
- *            (|err| ~ 1e-5 of fp32; the default, meets the 1e-4 parity bound);
- *   BF16   : hi part only, 1 MFMA per MAC (|err| ~ 1e-3, stated tolerance 5e-3). */
-enum ListPrecision { LIST_PREC_BF16X3 = 0, LIST_PREC_BF16 = 1 };
+/* Arithmetic of the implicit MLP (the gathers and all interpolation are always fp32; the
+ * accumulation is always fp32):
+ *   BF16X3 : operands split into bf16 hi+lo, 3 MFMA products per MAC (measured |err| < 1e-6 of
+ *            the fp32 reference: fp32-grade);
+ *   BF16   : bf16 operands, 1 MFMA per MAC (measured |err| ~ 3e-4, stated tolerance 5e-3);
+ *   FP16   : fp16 operands (11-bit significand), 1 MFMA per MAC (measured |err| ~ 4e-5, inside
+ *            the 1e-4 parity bound); magnitudes above 65504 saturate.
+ * The packed weights (list_prep_mlp_weights) are specific to {BF16X3,BF16} or {FP16}. */
+enum ListPrecision { LIST_PREC_BF16X3 = 0, LIST_PREC_BF16 = 1, LIST_PREC_FP16 = 2 };
 
 /* One 2-D feature map [B,C,H,W] float32 with element strides (NCHW or channels-last). */
 typedef struct ListMap2D {
@@ -79,6 +83,7 @@ typedef struct ListMlpWeights {
   int32_t F, H1, H2, H3;
   int32_t vox_C[LIST_N_VOX_LEVELS];   /* channel count per voxel level (feature order k=c*7+j) */
   int32_t img_C;                      /* total perceptual channels (1024) */
+  int32_t precision;                  /* enum ListPrecision the packed copy is built for */
 } ListMlpWeights;
 
 /* ---------------------------------------------------------------------------------------
@@ -136,6 +141,8 @@ typedef struct ListQueryArgs {
   int32_t precision;                    /* enum ListPrecision */
   void* const* stage_events;            /* optional: LIST_N_STAGES hipEvent_t handles (host array), */
                                         /*   recorded on the stream at the stage boundaries below   */
+  int32_t no_sort;                      /* 0: process points in Morton order (default; results are  */
+                                        /*   bit-identical either way), 1: keep the caller's order  */
 } ListQueryArgs;
 
 /* stage boundaries recorded into ListQueryArgs.stage_events (per row chunk; a later chunk
@@ -178,7 +185,8 @@ int list_gather_features_fwd(const ListQueryArgs* args, float* out, void* stream
 /* ---------------------------------------------------------------------------------------
  * list_gemm_nt -- test/diagnostic entry for the MFMA kernel used by the MLP:
  * out[M][N] = act(A[M][K] . W[N][K]^T + bias), A and W given as bf16 hi/lo planes
- * (lo may be NULL with LIST_PREC_BF16).  M % 256 == 0, N % 256 == 0, K % 32 == 0.
+ * (lo may be NULL with LIST_PREC_BF16; with LIST_PREC_FP16 the hi planes hold fp16 and lo is
+ * ignored).  M % 256 == 0, N % 256 == 0, K % 32 == 0.
  */
 int list_gemm_nt(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo,
                  const float* bias, float* out, int32_t M, int32_t N, int32_t K, int32_t relu,
@@ -186,6 +194,8 @@ int list_gemm_nt(const void* a_hi, const void* a_lo, const void* w_hi, const voi
 
 /* fp32 -> bf16 hi/lo planes (round-to-nearest-even; lo = bf16(x - hi)). n % 4 == 0. */
 int list_split_bf16(const float* x, void* hi, void* lo, int64_t n, void* stream);
+/* fp32 -> fp16 (round-to-nearest-even, saturating at +-65504). n % 4 == 0. */
+int list_to_fp16(const float* x, void* out, int64_t n, void* stream);
 
 const char* list_last_error(void);
 int list_abi_version(void);

@@ -74,7 +74,7 @@ def build_parser():
     p.add_argument("--test_checkpoint", default="best_model_test.pt.tar")
     p.add_argument("--testlist_file", default="./data/DISN_split/testlist_all.lst")
     # --- MI355X path
-    p.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"],
+    p.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp16", "bf16"],
                    help="arithmetic of the implicit MLP on the HIP path")
     p.add_argument("--synthetic_len", type=int, default=64, help="items per epoch of the synthetic datasets")
     p.add_argument("--num_workers", type=int, default=0)

@@ -16,7 +16,7 @@ struct Pt { float x, y, z; int b; bool valid; };
 __device__ __forceinline__ Pt load_point(const GatherParams& g, int row) {
   Pt p;
   p.valid = row < g.n_valid;
-  const int64_t gp = g.p_begin + (p.valid ? row : 0);
+  const int64_t gp = g.p_begin + (p.valid ? (g.order ? g.order[row] : row) : 0);
   p.b = (int)(gp / g.N);
   const int n = (int)(gp - (int64_t)p.b * g.N);
   const float* q = g.query + (int64_t)p.b * g.q_sb + (int64_t)n * g.q_sn;
@@ -85,7 +85,7 @@ __device__ __forceinline__ void stencil_point(const Pt& p, float& x, float& y, f
   z = p.z + (J == 5 ? -kDisp : J == 6 ? kDisp : 0.f);
 }
 
-template <int C, int J>
+template <int C, int J, int FMT>
 __device__ __forceinline__ void gather_one(const GatherParams& g, const ListVoxLevel& lv,
                                            const float* __restrict__ base, const Pt& p,
                                            int64_t out_off) {
@@ -94,14 +94,11 @@ __device__ __forceinline__ void gather_one(const GatherParams& g, const ListVoxL
   const Axis ax = axis_setup(x, lv.W), ay = axis_setup(y, lv.H), az = axis_setup(z, lv.D);
   float4 v = trilinear4(base, C, lv.H, lv.W, ax, ay, az);
   if (!p.valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
-  uint2 hi, lo;
-  split4(v, hi, lo);
-  *(uint2*)(g.x_hi + out_off + J * C) = hi;
-  *(uint2*)(g.x_lo + out_off + J * C) = lo;
+  store_feat4<FMT>(g.x_hi, g.x_lo, out_off + J * C, v);
 }
 
 // grid = rows/64, block = 256.  LP = C/4 lanes share a point; a wave covers 64/LP points.
-template <int C>
+template <int C, int FMT>
 __global__ __launch_bounds__(256) void k_gather_vox(GatherParams g, ListVoxLevel lv, int col_off) {
   constexpr int LP = C / 4;              // lanes per point
   constexpr int PW = 64 / LP;            // points per wave per iteration
@@ -109,19 +106,20 @@ __global__ __launch_bounds__(256) void k_gather_vox(GatherParams g, ListVoxLevel
   constexpr int RB = 4 * PW * ITERS;     // rows per workgroup (64, 128 or 256: divides g.rows)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int quad = lane % LP, psub = lane / LP;
+  const int blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
 #pragma unroll 1
   for (int it = 0; it < ITERS; ++it) {
-    const int row = blockIdx.x * RB + it * (4 * PW) + wave * PW + psub;
+    const int row = blk * RB + it * (4 * PW) + wave * PW + psub;
     const Pt p = load_point(g, row);
     const float* base = lv.data + (int64_t)p.b * lv.image_stride + quad * 4;
     const int64_t out_off = (int64_t)row * g.Kp + col_off + quad * 4;
-    gather_one<C, 0>(g, lv, base, p, out_off);
-    gather_one<C, 1>(g, lv, base, p, out_off);
-    gather_one<C, 2>(g, lv, base, p, out_off);
-    gather_one<C, 3>(g, lv, base, p, out_off);
-    gather_one<C, 4>(g, lv, base, p, out_off);
-    gather_one<C, 5>(g, lv, base, p, out_off);
-    gather_one<C, 6>(g, lv, base, p, out_off);
+    gather_one<C, 0, FMT>(g, lv, base, p, out_off);
+    gather_one<C, 1, FMT>(g, lv, base, p, out_off);
+    gather_one<C, 2, FMT>(g, lv, base, p, out_off);
+    gather_one<C, 3, FMT>(g, lv, base, p, out_off);
+    gather_one<C, 4, FMT>(g, lv, base, p, out_off);
+    gather_one<C, 5, FMT>(g, lv, base, p, out_off);
+    gather_one<C, 6, FMT>(g, lv, base, p, out_off);
   }
 }
 
@@ -172,37 +170,36 @@ __device__ __forceinline__ float4 bilinear4(const float* __restrict__ img, const
 }
 
 // grid = rows/64, block = 256: the block walks its 64 points, lanes over channel quads.
+template <int FMT>
 __global__ __launch_bounds__(256) void k_gather_img(GatherParams g, const float* __restrict__ img_map,
                                                     const float* __restrict__ trans_mat, int ms,
                                                     int Ct, float clamp_hi, int col_off) {
   const int nq = Ct / 4;
+  const int blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
 #pragma unroll 2
   for (int i = 0; i < kGatherRows; ++i) {
-    const int row = blockIdx.x * kGatherRows + i;
+    const int row = blk * kGatherRows + i;
     const Pt p = load_point(g, row);
     const Proj pr = project(trans_mat + p.b * 12, p.x, p.y, p.z, ms, Ct, clamp_hi);
     const float* img = img_map + (int64_t)p.b * ms * ms * Ct;
     for (int q = threadIdx.x; q < nq; q += 256) {
       float4 v = bilinear4(img + q * 4, pr);
       if (!p.valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      uint2 hi, lo;
-      split4(v, hi, lo);
-      const int64_t o = (int64_t)row * g.Kp + col_off + q * 4;
-      *(uint2*)(g.x_hi + o) = hi;
-      *(uint2*)(g.x_lo + o) = lo;
+      store_feat4<FMT>(g.x_hi, g.x_lo, (int64_t)row * g.Kp + col_off + q * 4, v);
     }
   }
 }
 
 // Pre-pooled perceptual features [B,img_C,N] (VoxelDecoder2.forward's third argument) -> X.
 // lane = row so reads are coalesced along N.
+template <int FMT>
 __global__ __launch_bounds__(256) void k_copy_percep(GatherParams g, const float* __restrict__ pf,
                                                      int64_t sb, int64_t sc, int64_t sn, int Ct,
                                                      int col_off) {
   const int row = blockIdx.x * 256 + threadIdx.x;
   if (row >= g.rows) return;
   const bool valid = row < g.n_valid;
-  const int64_t gp = g.p_begin + (valid ? row : 0);
+  const int64_t gp = g.p_begin + (valid ? (g.order ? g.order[row] : row) : 0);
   const int b = (int)(gp / g.N);
   const int n = (int)(gp - (int64_t)b * g.N);
   const float* src = pf + (int64_t)b * sb + (int64_t)n * sn;
@@ -210,11 +207,7 @@ __global__ __launch_bounds__(256) void k_copy_percep(GatherParams g, const float
     float4 v = make_float4(src[(int64_t)c * sc], src[(int64_t)(c + 1) * sc],
                            src[(int64_t)(c + 2) * sc], src[(int64_t)(c + 3) * sc]);
     if (!valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint2 hi, lo;
-    split4(v, hi, lo);
-    const int64_t o = (int64_t)row * g.Kp + col_off + c;
-    *(uint2*)(g.x_hi + o) = hi;
-    *(uint2*)(g.x_lo + o) = lo;
+    store_feat4<FMT>(g.x_hi, g.x_lo, (int64_t)row * g.Kp + col_off + c, v);
   }
 }
 
@@ -236,12 +229,12 @@ __device__ __forceinline__ float trilinear1(const float* __restrict__ base, int 
   return acc;
 }
 
+template <int FMT>
 __device__ __forceinline__ void put(const GatherParams& g, int64_t o, float v) {
-  const unsigned short h = f2bf(v);
-  g.x_hi[o] = h;
-  g.x_lo[o] = f2bf(v - bf2f(h));
+  store_feat1<FMT>(g.x_hi, g.x_lo, o, v);
 }
 
+template <int FMT>
 __global__ __launch_bounds__(256) void k_gather_tail(GatherParams g, TailLevels tl, int xyz_off,
                                                      int F) {
   const int row = blockIdx.x * 256 + threadIdx.x;
@@ -258,27 +251,109 @@ __global__ __launch_bounds__(256) void k_gather_tail(GatherParams g, TailLevels 
       const float z = p.z + (j == 5 ? -kDisp : j == 6 ? kDisp : 0.f);
       const Axis ax = axis_setup(x, lv.W), ay = axis_setup(y, lv.H), az = axis_setup(z, lv.D);
       const float v = trilinear1(base, lv.H, lv.W, ax, ay, az);
-      put(g, ro + tl.off[l] + j, p.valid ? v : 0.f);
+      put<FMT>(g, ro + tl.off[l] + j, p.valid ? v : 0.f);
     }
   }
-  put(g, ro + xyz_off + 0, p.valid ? p.x : 0.f);     // p_features, modules.py:257
-  put(g, ro + xyz_off + 1, p.valid ? p.y : 0.f);
-  put(g, ro + xyz_off + 2, p.valid ? p.z : 0.f);
-  for (int k = F; k < g.Kp; ++k) { g.x_hi[ro + k] = 0; g.x_lo[ro + k] = 0; }
+  put<FMT>(g, ro + xyz_off + 0, p.valid ? p.x : 0.f);     // p_features, modules.py:257
+  put<FMT>(g, ro + xyz_off + 1, p.valid ? p.y : 0.f);
+  put<FMT>(g, ro + xyz_off + 2, p.valid ? p.z : 0.f);
+  for (int k = F; k < g.Kp; ++k) {
+    g.x_hi[ro + k] = 0;
+    if (FMT == FMT_BF16_SPLIT) g.x_lo[ro + k] = 0;
+  }
+}
+
+// ---- Morton ordering of the query points -------------------------------------------------------------
+// Random query points make every tap a cold line.  Rows are therefore processed in (image, Morton
+// cell) order, a counting sort on key = (b % 64) * 4096 + morton(16^3 cell): consecutive rows (and so
+// the workgroups resident at any moment, on every XCD) sample one small region of the maps, which
+// turns most taps into L1/L2 hits.  Results are independent of the row order bit for bit (every row
+// is computed on its own); the order inside a cell comes from atomics and is not deterministic.
+__device__ __forceinline__ unsigned spread3(unsigned v) {      // 4 bits -> every third bit
+  v = (v | (v << 4)) & 0x0C3u;
+  v = (v | (v << 2)) & 0x249u;
+  return v;
+}
+__device__ __forceinline__ int sort_key(const GatherParams& g, int i, int b_first) {
+  const int64_t gp = g.p_begin + i;
+  const int b = (int)(gp / g.N);
+  const int n = (int)(gp - (int64_t)b * g.N);
+  const float* q = g.query + (int64_t)b * g.q_sb + (int64_t)n * g.q_sn;
+  unsigned c[3];
+  const int perm[3] = {g.perm0, g.perm1, g.perm2};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float v = (q[(int64_t)perm[a] * g.q_sc] * g.scale + 1.f) * (0.5f * kSortCellsPerAxis);
+    c[a] = (unsigned)fminf(fmaxf(v, 0.f), (float)(kSortCellsPerAxis - 1));
+  }
+  const unsigned m = spread3(c[0]) | (spread3(c[1]) << 1) | (spread3(c[2]) << 2);
+  return ((b - b_first) % kSortImages) * kSortCells + (int)m;
+}
+
+__global__ __launch_bounds__(256) void k_sort_hist(GatherParams g, int b_first, int* __restrict__ keys,
+                                                   int* __restrict__ bins) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.n_valid) return;
+  const int k = sort_key(g, i, b_first);
+  keys[i] = k;
+  atomicAdd(&bins[k], 1);
+}
+
+// exclusive scan of nbins (a multiple of 4096) counters by ONE workgroup of 1024 threads
+__global__ __launch_bounds__(1024) void k_sort_scan(int* __restrict__ bins, int nbins) {
+  __shared__ int part[1024];
+  const int PER = nbins / 1024;
+  int* mine = bins + threadIdx.x * PER;
+  int sum = 0;
+  for (int i = 0; i < PER; ++i) sum += mine[i];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = part[threadIdx.x] - sum;
+  for (int i = 0; i < PER; ++i) { const int c = mine[i]; mine[i] = run; run += c; }
+}
+
+__global__ __launch_bounds__(256) void k_sort_scatter(int n_valid, const int* __restrict__ keys,
+                                                      int* __restrict__ bins, int* __restrict__ order) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_valid) return;
+  order[atomicAdd(&bins[keys[i]], 1)] = i;
+}
+
+hipError_t launch_sort_points(const GatherParams& g, int* order, int* keys, int* bins, hipStream_t s) {
+  const int b_first = (int)(g.p_begin / g.N);
+  const int64_t b_last = (g.p_begin + g.n_valid - 1) / g.N;
+  const int nslots = (int)((b_last - b_first + 1 < kSortImages) ? (b_last - b_first + 1) : kSortImages);
+  const int nbins = nslots * kSortCells;
+  hipError_t e = hipMemsetAsync(bins, 0, (size_t)nbins * sizeof(int), s);
+  if (e != hipSuccess) return e;
+  const unsigned nb = (unsigned)((g.n_valid + 255) / 256);
+  GatherParams raw = g;
+  raw.order = nullptr;
+  hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(256), 0, s, raw, b_first, keys, bins);
+  hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, s, bins, nbins);
+  hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(256), 0, s, g.n_valid, keys, bins, order);
+  return hipGetLastError();
 }
 
 // ---- launch ----------------------------------------------------------------------------------------
-template <int C>
+template <int C, int FMT>
 static hipError_t launch_vox_level(const GatherParams& g, const ListVoxLevel& lv, int col_off,
                                    hipStream_t s) {
   constexpr int PW = 64 / (C / 4);
   constexpr int RB = (4 * PW >= kGatherRows) ? 4 * PW : kGatherRows;
-  hipLaunchKernelGGL(k_gather_vox<C>, dim3(g.rows / RB), dim3(256), 0, s, g, lv, col_off);
+  hipLaunchKernelGGL((k_gather_vox<C, FMT>), dim3(g.rows / RB), dim3(256), 0, s, g, lv, col_off);
   return hipGetLastError();
 }
 
-hipError_t launch_gather(const GatherParams& g, const FeatLayout& L, const ListQueryArgs& a,
-                         hipStream_t s) {
+template <int FMT>
+static hipError_t launch_gather_fmt(const GatherParams& g, const FeatLayout& L, const ListQueryArgs& a,
+                                    hipStream_t s) {
   hipError_t e = hipSuccess;
   TailLevels tl;
   tl.n = 0;
@@ -286,13 +361,13 @@ hipError_t launch_gather(const GatherParams& g, const FeatLayout& L, const ListQ
     const ListVoxLevel& lv = a.vox[l];
     if (lv.C == 1) { tl.lv[tl.n] = lv; tl.off[tl.n] = L.vox_off[l]; ++tl.n; continue; }
     switch (lv.C) {
-      case 4: e = launch_vox_level<4>(g, lv, L.vox_off[l], s); break;
-      case 8: e = launch_vox_level<8>(g, lv, L.vox_off[l], s); break;
-      case 16: e = launch_vox_level<16>(g, lv, L.vox_off[l], s); break;
-      case 32: e = launch_vox_level<32>(g, lv, L.vox_off[l], s); break;
-      case 64: e = launch_vox_level<64>(g, lv, L.vox_off[l], s); break;
-      case 128: e = launch_vox_level<128>(g, lv, L.vox_off[l], s); break;
-      case 256: e = launch_vox_level<256>(g, lv, L.vox_off[l], s); break;
+      case 4: e = launch_vox_level<4, FMT>(g, lv, L.vox_off[l], s); break;
+      case 8: e = launch_vox_level<8, FMT>(g, lv, L.vox_off[l], s); break;
+      case 16: e = launch_vox_level<16, FMT>(g, lv, L.vox_off[l], s); break;
+      case 32: e = launch_vox_level<32, FMT>(g, lv, L.vox_off[l], s); break;
+      case 64: e = launch_vox_level<64, FMT>(g, lv, L.vox_off[l], s); break;
+      case 128: e = launch_vox_level<128, FMT>(g, lv, L.vox_off[l], s); break;
+      case 256: e = launch_vox_level<256, FMT>(g, lv, L.vox_off[l], s); break;
       default: return hipErrorInvalidValue;
     }
     if (e != hipSuccess) return e;
@@ -300,17 +375,23 @@ hipError_t launch_gather(const GatherParams& g, const FeatLayout& L, const ListQ
   if (a.stage_events && a.stage_events[LIST_STAGE_VOX])
     (void)hipEventRecord((hipEvent_t)a.stage_events[LIST_STAGE_VOX], s);
   if (a.percep_feat) {
-    hipLaunchKernelGGL(k_copy_percep, dim3((g.rows + 255) / 256), dim3(256), 0, s, g, a.percep_feat,
-                       a.pf_sb, a.pf_sc, a.pf_sn, L.img_C, L.img_off);
+    hipLaunchKernelGGL(k_copy_percep<FMT>, dim3((g.rows + 255) / 256), dim3(256), 0, s, g,
+                       a.percep_feat, a.pf_sb, a.pf_sc, a.pf_sn, L.img_C, L.img_off);
   } else {
-    hipLaunchKernelGGL(k_gather_img, dim3(g.rows / kGatherRows), dim3(256), 0, s, g, a.img_map,
+    hipLaunchKernelGGL(k_gather_img<FMT>, dim3(g.rows / kGatherRows), dim3(256), 0, s, g, a.img_map,
                        a.trans_mat, a.map_size, L.img_C, a.clamp_hi, L.img_off);
   }
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_gather_tail, dim3((g.rows + 255) / 256), dim3(256), 0, s, g, tl, L.xyz_off,
+  hipLaunchKernelGGL(k_gather_tail<FMT>, dim3((g.rows + 255) / 256), dim3(256), 0, s, g, tl, L.xyz_off,
                      L.F);
   return hipGetLastError();
+}
+
+hipError_t launch_gather(const GatherParams& g, const FeatLayout& L, const ListQueryArgs& a,
+                         hipStream_t s) {
+  return g.fmt == FMT_FP16 ? launch_gather_fmt<FMT_FP16>(g, L, a, s)
+                           : launch_gather_fmt<FMT_BF16_SPLIT>(g, L, a, s);
 }
 
 // ---- diagnostics: X (gather order, hi+lo) -> out[B][F][N] in the reference order ---------------------
@@ -322,10 +403,11 @@ __global__ __launch_bounds__(256) void k_features_out(GatherParams g, FeatLayout
   const int row = (int)(i / L.Kp), kp = (int)(i - (int64_t)row * L.Kp);
   const int kr = ref_index_of(L, kp);
   if (kr < 0) return;
-  const int64_t gp = g.p_begin + row;
+  const int64_t gp = g.p_begin + (g.order ? g.order[row] : row);
   const int b = (int)(gp / g.N);
   const int n = (int)(gp - (int64_t)b * g.N);
-  out[((int64_t)b * L.F + kr) * g.N + n] = bf2f(g.x_hi[i]) + bf2f(g.x_lo[i]);
+  out[((int64_t)b * L.F + kr) * g.N + n] =
+      g.fmt == FMT_FP16 ? h2f(g.x_hi[i]) : bf2f(g.x_hi[i]) + bf2f(g.x_lo[i]);
 }
 
 hipError_t launch_features_out(const GatherParams& g, const FeatLayout& L, float* out, int B,

@@ -19,8 +19,26 @@ namespace list {
 
 constexpr int BM = 256, BN = 256, BK = 32;
 constexpr int kPlaneBytes = BM * BK * 2;        // 16 KB: one operand plane of one stage
-constexpr int kStageBytes = 4 * kPlaneBytes;    // A_hi, A_lo, W_hi, W_lo
-constexpr int kLdsBytes = 2 * kStageBytes;      // 128 KB
+constexpr int kLdsBytes = 8 * kPlaneBytes;      // 128 KB = 2 stages x 4 planes or 4 stages x 2 planes
+
+// Software pipeline.  A stage = the operand planes of one K-step: {A_hi, A_lo, W_hi, W_lo} (TERMS = 3,
+// 64 KB, 2 stages) or {A, W} (TERMS = 1, 32 KB, 4 stages).  LDS-DMA loads run D = NST-1 K-steps
+// ahead; the only waits in the loop are a COUNTED s_waitcnt vmcnt (the wave's own pieces of the
+// oldest stage have landed, the younger stages stay in flight) followed by ONE raw s_barrier (every
+// wave's pieces have landed, and every wave is done reading the buffer about to be refilled).
+template <int TERMS> struct Pipe {
+  static constexpr int kPlanes = TERMS == 3 ? 4 : 2;
+  static constexpr int kStageBytes = kPlanes * kPlaneBytes;
+  static constexpr int kStages = kLdsBytes / kStageBytes;       // 2 or 4
+  static constexpr int kAhead = kStages - 1;                    // 1 or 3
+  static constexpr int kLoadsPerStage = 2 * kPlanes;            // glds issued per wave per stage
+  static constexpr int kWOff = (TERMS == 3 ? 2 : 1) * kPlaneBytes;
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
 __device__ __forceinline__ void glds16(const char* g, char* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -44,12 +62,23 @@ __device__ __forceinline__ void stage_tiles(const GemmParams& p, char* sbase, in
     char* l = sbase + rb * 1024;
     glds16(p.a_hi + aoff, l);
     if (TERMS == 3) glds16(p.a_lo + aoff, l + kPlaneBytes);
-    glds16(p.w_hi + woff, l + 2 * kPlaneBytes);
-    if (TERMS == 3) glds16(p.w_lo + woff, l + 3 * kPlaneBytes);
+    glds16(p.w_hi + woff, l + Pipe<TERMS>::kWOff);
+    if (TERMS == 3) glds16(p.w_lo + woff, l + Pipe<TERMS>::kWOff + kPlaneBytes);
   }
 }
 
-template <int TERMS, int EPI>
+template <int FP16>
+__device__ __forceinline__ f32x16 mfma(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  if (FP16)   // same registers, fp16 interpretation: v_mfma_f32_32x32x16_f16
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
+                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <int FP16>
+__device__ __forceinline__ unsigned short to_half_plane(float v) { return FP16 ? f2h(v) : f2bf(v); }
+
+// TERMS = 3: bf16 hi/lo split (3 products); TERMS = 1: single plane, bf16 (FP16 = 0) or fp16 (FP16 = 1)
+template <int TERMS, int EPI, int FP16>
 __global__ __launch_bounds__(512, 2) void k_gemm_nt(GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
   const int lane = threadIdx.x & 63;
@@ -60,11 +89,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(GemmParams p) {
   // run of tiles so the N-tiles of one M-tile (same A rows) run on one L2.  Bijective for any grid.
   const int tiles_n = p.N / BN;
   const int ntiles = (p.M / BM) * tiles_n;
-  int tile;
-  {
-    const int L = blockIdx.x, q = ntiles / 8, r = ntiles % 8, xcd = L % 8;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + L / 8;
-  }
+  const int tile = xcd_contiguous_block(blockIdx.x, ntiles);
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
 
   f32x16 acc[4][2];
@@ -80,13 +105,22 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(GemmParams p) {
   const int a_row_off = (wm * 128 + frow) * 64;
   const int w_row_off = (wn * 64 + frow) * 64;
 
+  using P = Pipe<TERMS>;
   const int nk = p.K / BK;
-  stage_tiles<TERMS>(p, smem, m0, n0, 0, wave, lane);
-  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < P::kAhead; ++s)
+    if (s < nk) stage_tiles<TERMS>(p, smem + s * P::kStageBytes, m0, n0, s * BK * 2, wave, lane);
   for (int t = 0; t < nk; ++t) {
-    const char* cur = smem + (t & 1) * kStageBytes;
-    if (t + 1 < nk)
-      stage_tiles<TERMS>(p, smem + ((t + 1) & 1) * kStageBytes, m0, n0, (t + 1) * BK * 2, wave, lane);
+    // stage t must have landed; stages t+1 .. t+kAhead-1 (those that exist) may stay in flight
+    const int younger = min(P::kAhead - 1, nk - 1 - t);
+    if (younger >= 2) wait_vmcnt<2 * P::kLoadsPerStage>();
+    else if (younger == 1) wait_vmcnt<P::kLoadsPerStage>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (t + P::kAhead < nk)
+      stage_tiles<TERMS>(p, smem + ((t + P::kAhead) % P::kStages) * P::kStageBytes, m0, n0,
+                         (t + P::kAhead) * BK * 2, wave, lane);
+    const char* cur = smem + (t % P::kStages) * P::kStageBytes;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       const int coff = ((2 * s2 + fh) ^ swz) << 4;
@@ -98,21 +132,20 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(GemmParams p) {
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        wh[j] = *(const bf16x8*)(cur + 2 * kPlaneBytes + w_row_off + j * 32 * 64 + coff);
-        if (TERMS == 3) wl[j] = *(const bf16x8*)(cur + 3 * kPlaneBytes + w_row_off + j * 32 * 64 + coff);
+        wh[j] = *(const bf16x8*)(cur + P::kWOff + w_row_off + j * 32 * 64 + coff);
+        if (TERMS == 3) wl[j] = *(const bf16x8*)(cur + P::kWOff + kPlaneBytes + w_row_off + j * 32 * 64 + coff);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           if (TERMS == 3) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], wh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], wl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma<0>(al[i], wh[j], acc[i][j]);
+            acc[i][j] = mfma<0>(ah[i], wl[j], acc[i][j]);
           }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], wh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma<FP16>(ah[i], wh[j], acc[i][j]);
         }
     }
-    __syncthreads();
   }
 
   // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -138,9 +171,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(GemmParams p) {
             of[off] = v;
           } else {
             v = fmaxf(v, 0.f);
-            const unsigned short h = f2bf(v);
+            const unsigned short h = to_half_plane<FP16>(v);
             oh[off] = h;
-            if (ol) ol[off] = f2bf(v - bf2f(h));
+            if (!FP16 && ol) ol[off] = f2bf(v - bf2f(h));
           }
         }
     }
@@ -173,7 +206,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(GemmParams p) {
         v += __shfl_xor(v, 1);
         part[i][e] = v;
       }
-    float* red = (float*)smem;                         // [4 (wn)][256 rows]; smem is idle now
+    __syncthreads();                                   // every wave is done reading the last stage
+    float* red = (float*)smem;                         // [4 (wn)][256 rows]
     if (col_in == 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -188,30 +222,33 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(GemmParams p) {
       const int row = m0 + threadIdx.x;
       if (row < p.n_valid) {
         const int rl = threadIdx.x;
-        p.sdf[row] = ((red[rl] + red[256 + rl]) + (red[512 + rl] + red[768 + rl])) + p.b3[0];
+        p.sdf[p.order ? p.order[row] : row] =
+            ((red[rl] + red[256 + rl]) + (red[512 + rl] + red[768 + rl])) + p.b3[0];
       }
     }
   }
 }
 
-template <int TERMS, int EPI>
+template <int TERMS, int EPI, int FP16>
 static hipError_t launch_one(const GemmParams& p, hipStream_t s) {
   const int ntiles = (p.M / BM) * (p.N / BN);
-  hipLaunchKernelGGL((k_gemm_nt<TERMS, EPI>), dim3(ntiles), dim3(512), 0, s, p);
+  hipLaunchKernelGGL((k_gemm_nt<TERMS, EPI, FP16>), dim3(ntiles), dim3(512), 0, s, p);
   return hipGetLastError();
+}
+
+template <int TERMS, int FP16>
+static hipError_t launch_epi(const GemmParams& p, int epi, hipStream_t s) {
+  if (epi == EPI_RELU_SPLIT) return launch_one<TERMS, EPI_RELU_SPLIT, FP16>(p, s);
+  if (epi == EPI_F32) return launch_one<TERMS, EPI_F32, FP16>(p, s);
+  return launch_one<TERMS, EPI_RELU_DOT, FP16>(p, s);
 }
 
 hipError_t launch_gemm(const GemmParams& p, int terms, int epi, hipStream_t s) {
   if (p.M % BM || p.N % BN || p.K % BK || p.M <= 0) return hipErrorInvalidValue;
   if (epi == EPI_RELU_DOT && p.N != BN) return hipErrorInvalidValue;
-  if (terms == 3) {
-    if (epi == EPI_RELU_SPLIT) return launch_one<3, EPI_RELU_SPLIT>(p, s);
-    if (epi == EPI_F32) return launch_one<3, EPI_F32>(p, s);
-    return launch_one<3, EPI_RELU_DOT>(p, s);
-  }
-  if (epi == EPI_RELU_SPLIT) return launch_one<1, EPI_RELU_SPLIT>(p, s);
-  if (epi == EPI_F32) return launch_one<1, EPI_F32>(p, s);
-  return launch_one<1, EPI_RELU_DOT>(p, s);
+  if (p.fmt == FMT_FP16) return launch_epi<1, 1>(p, epi, s);
+  if (terms == 3) return launch_epi<3, 0>(p, epi, s);
+  return launch_epi<1, 0>(p, epi, s);
 }
 
 }  // namespace list

@@ -81,6 +81,8 @@ GatherParams make_gather(const ListQueryArgs* a, const FeatLayout& L, const Work
   g.x_hi = (unsigned short*)((char*)a->workspace + ws.x_hi);
   g.x_lo = (unsigned short*)((char*)a->workspace + ws.x_lo);
   g.Kp = L.Kp;
+  g.fmt = a->precision == LIST_PREC_FP16 ? FMT_FP16 : FMT_BF16_SPLIT;
+  g.order = nullptr;
   return g;
 }
 
@@ -88,7 +90,10 @@ GatherParams make_gather(const ListQueryArgs* a, const FeatLayout& L, const Work
 int64_t chunk_rows_for(size_t bytes, int64_t P, int Kp, int H1, int H2) {
   int64_t want = (P + kRowTile - 1) / kRowTile * kRowTile;
   if (want > kMaxChunkRows) want = kMaxChunkRows;
-  int64_t fit = (int64_t)(bytes / workspace_row_bytes(Kp, H1, H2)) / kRowTile * kRowTile;
+  if (workspace_layout(want, Kp, H1, H2).total <= bytes) return want;
+  if (bytes < workspace_fixed_bytes()) return 0;
+  int64_t fit = (int64_t)((bytes - workspace_fixed_bytes()) / workspace_row_bytes(Kp, H1, H2) + kRowTile)
+                / kRowTile * kRowTile;
   if (fit > want) fit = want;
   while (fit >= kRowTile && workspace_layout(fit, Kp, H1, H2).total > bytes) fit -= kRowTile;
   return fit >= kRowTile ? fit : 0;
@@ -173,6 +178,8 @@ int list_prep_vox_maps(const ListMap3D maps[LIST_N_VOX_LEVELS], int32_t B, float
 // ------------------------------------------------------------------------------------------ weights
 static int weights_layout(const ListMlpWeights* w, FeatLayout* L) {
   if (!w) return fail(LIST_ERR_ARG, "weights is NULL");
+  if (w->precision < LIST_PREC_BF16X3 || w->precision > LIST_PREC_FP16)
+    return fail(LIST_ERR_ARG, "weights precision=%d", w->precision);
   if (!w->w0 || !w->b0 || !w->w1 || !w->b1 || !w->w2 || !w->b2 || !w->w3 || !w->b3)
     return fail(LIST_ERR_ARG, "a weight pointer is NULL");
   if (!make_layout(w->vox_C, w->img_C, L)) return fail(LIST_ERR_UNSUPPORTED, "unsupported channel counts");
@@ -221,7 +228,8 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
   if (a->F != L.F) return fail(LIST_ERR_SHAPE, "F=%d but channels give %d", a->F, L.F);
   if (a->H1 % 256 || a->H2 % 256 || a->H3 != 256 || a->H1 <= 0 || a->H2 <= 0)
     return fail(LIST_ERR_UNSUPPORTED, "hidden sizes %d/%d/%d", a->H1, a->H2, a->H3);
-  if (a->precision != LIST_PREC_BF16X3 && a->precision != LIST_PREC_BF16)
+  if (a->precision != LIST_PREC_BF16X3 && a->precision != LIST_PREC_BF16 &&
+      a->precision != LIST_PREC_FP16)
     return fail(LIST_ERR_ARG, "precision=%d", a->precision);
   if (!aligned16(a->workspace)) return fail(LIST_ERR_SHAPE, "workspace must be 16-byte aligned");
   const int64_t P = (int64_t)a->B * a->N;
@@ -245,12 +253,20 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
         (void)hipEventRecord((hipEvent_t)a->stage_events[stage], s);
     };
     mark(LIST_STAGE_BEGIN);
-    hipError_t e = launch_gather(g, L, *a, s);
+    hipError_t e = hipSuccess;
+    if (!a->no_sort) {
+      int* order = (int*)(wsb + ws.order);
+      e = launch_sort_points(g, order, (int*)(wsb + ws.keys), (int*)(wsb + ws.bins), s);
+      if (e != hipSuccess) return hip_fail(e, "sort launch");
+      g.order = order;
+    }
+    e = launch_gather(g, L, *a, s);
     if (e != hipSuccess) return hip_fail(e, "gather launch");
     mark(LIST_STAGE_IMG);
 
     GemmParams gp;
     memset(&gp, 0, sizeof(gp));
+    gp.fmt = g.fmt;
     // fc_0 + ReLU
     gp.a_hi = wsb + ws.x_hi; gp.a_lo = wsb + ws.x_lo;
     gp.w_hi = wp + pk.w0_hi; gp.w_lo = wp + pk.w0_lo;
@@ -280,7 +296,7 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
     gp.N = a->H3; gp.K = a->H2;
     gp.out_hi = nullptr; gp.out_lo = nullptr;
     gp.w3 = (const float*)(wp + pk.w3); gp.b3 = (const float*)(wp + pk.b3);
-    gp.sdf = a->sdf + p0; gp.n_valid = n_valid;
+    gp.sdf = a->sdf + p0; gp.n_valid = n_valid; gp.order = g.order;
     e = launch_gemm(gp, terms, EPI_RELU_DOT, s);
     if (e != hipSuccess) return hip_fail(e, "fc_2/fc_out launch");
     mark(LIST_STAGE_FC2);
@@ -330,6 +346,7 @@ int list_gemm_nt(const void* a_hi, const void* a_lo, const void* w_hi, const voi
                  int32_t precision, void* stream) {
   if (!a_hi || !w_hi || !out) return fail(LIST_ERR_ARG, "NULL pointer");
   if (precision == LIST_PREC_BF16X3 && (!a_lo || !w_lo)) return fail(LIST_ERR_ARG, "lo planes missing");
+  if (precision < LIST_PREC_BF16X3 || precision > LIST_PREC_FP16) return fail(LIST_ERR_ARG, "precision=%d", precision);
   if (M <= 0 || M % 256 || N <= 0 || N % 256 || K <= 0 || K % 32)
     return fail(LIST_ERR_SHAPE, "M=%d N=%d K=%d (need M,N %% 256 == 0, K %% 32 == 0)", M, N, K);
   if (!aligned16(a_hi) || !aligned16(w_hi) || (a_lo && !aligned16(a_lo)) || (w_lo && !aligned16(w_lo)))
@@ -339,6 +356,7 @@ int list_gemm_nt(const void* a_hi, const void* a_lo, const void* w_hi, const voi
   gp.a_hi = (const char*)a_hi; gp.a_lo = (const char*)a_lo;
   gp.w_hi = (const char*)w_hi; gp.w_lo = (const char*)w_lo;
   gp.bias = bias; gp.M = M; gp.N = N; gp.K = K; gp.out_f32 = out; gp.relu = relu;
+  gp.fmt = precision == LIST_PREC_FP16 ? FMT_FP16 : FMT_BF16_SPLIT;
   hipError_t e = launch_gemm(gp, precision == LIST_PREC_BF16X3 ? 3 : 1, EPI_F32, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "gemm launch");
   return LIST_OK;
@@ -348,8 +366,18 @@ int list_split_bf16(const float* x, void* hi, void* lo, int64_t n, void* stream)
   if (!x || !hi) return fail(LIST_ERR_ARG, "NULL pointer");
   if (n <= 0 || n % 4) return fail(LIST_ERR_SHAPE, "n=%lld must be a positive multiple of 4", (long long)n);
   if (!aligned16(x)) return fail(LIST_ERR_SHAPE, "x must be 16-byte aligned");
-  hipError_t e = launch_split(x, (unsigned short*)hi, (unsigned short*)lo, n, (hipStream_t)stream);
+  hipError_t e = launch_split(x, (unsigned short*)hi, (unsigned short*)lo, n, FMT_BF16_SPLIT,
+                              (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "split launch");
+  return LIST_OK;
+}
+
+int list_to_fp16(const float* x, void* out, int64_t n, void* stream) {
+  if (!x || !out) return fail(LIST_ERR_ARG, "NULL pointer");
+  if (n <= 0 || n % 4) return fail(LIST_ERR_SHAPE, "n=%lld must be a positive multiple of 4", (long long)n);
+  if (!aligned16(x)) return fail(LIST_ERR_SHAPE, "x must be 16-byte aligned");
+  hipError_t e = launch_split(x, (unsigned short*)out, nullptr, n, FMT_FP16, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "to_fp16 launch");
   return LIST_OK;
 }
 

@@ -10,6 +10,7 @@
 namespace list {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int kRowTile = 256;       // GEMM BM: workspace rows are padded to this
@@ -31,6 +32,55 @@ __device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
   const unsigned short l2 = f2bf(v.z - bf2f(h2)), l3 = f2bf(v.w - bf2f(h3));
   hi = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
   lo = make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));
+}
+
+// ---- fp16 (single plane) -------------------------------------------------------------------
+__device__ __forceinline__ unsigned short f2h(float x) {
+  x = fminf(fmaxf(x, -65504.f), 65504.f);                   // saturate (NaN passes through)
+  return __builtin_bit_cast(unsigned short, (_Float16)x);   // v_cvt_f16_f32, RNE
+}
+__device__ __forceinline__ float h2f(unsigned short h) {
+  return (float)__builtin_bit_cast(_Float16, h);
+}
+__device__ __forceinline__ uint2 half4(const float4& v) {
+  return make_uint2((unsigned)f2h(v.x) | ((unsigned)f2h(v.y) << 16),
+                    (unsigned)f2h(v.z) | ((unsigned)f2h(v.w) << 16));
+}
+enum { FMT_BF16_SPLIT = 0, FMT_FP16 = 1 };     // element format of X / H / packed weights
+
+// store 4 consecutive features of one row
+template <int FMT>
+__device__ __forceinline__ void store_feat4(unsigned short* x_hi, unsigned short* x_lo, int64_t off,
+                                            const float4& v) {
+  if (FMT == FMT_FP16) {
+    *(uint2*)(x_hi + off) = half4(v);
+  } else {
+    uint2 hi, lo;
+    split4(v, hi, lo);
+    *(uint2*)(x_hi + off) = hi;
+    *(uint2*)(x_lo + off) = lo;
+  }
+}
+template <int FMT>
+__device__ __forceinline__ void store_feat1(unsigned short* x_hi, unsigned short* x_lo, int64_t off,
+                                            float v) {
+  if (FMT == FMT_FP16) {
+    x_hi[off] = f2h(v);
+  } else {
+    const unsigned short h = f2bf(v);
+    x_hi[off] = h;
+    x_lo[off] = f2bf(v - bf2f(h));
+  }
+}
+
+// ---- XCD-aware workgroup order ---------------------------------------------------------------
+// Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an XCD and its 4 MB L2).  This
+// bijection hands XCD k the k-th CONTIGUOUS eighth of the logical block range, so that -- with rows
+// in Morton order -- every L2 serves one compact region of the maps instead of all of them.
+// Placement only affects speed, never results.
+__device__ __forceinline__ int xcd_contiguous_block(int bid, int nblocks) {
+  const int q = nblocks / 8, r = nblocks % 8, xcd = bid % 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
 }
 
 // ---- feature layout ---------------------------------------------------------------------
@@ -111,13 +161,20 @@ inline PackedMlp packed_mlp_layout(int Kp, int H1, int H2, int H3) {
 }
 
 // ---- per-chunk workspace --------------------------------------------------------------------
+constexpr int kSortCellsPerAxis = 16;                        // Morton cells per axis per image
+constexpr int kSortCells = kSortCellsPerAxis * kSortCellsPerAxis * kSortCellsPerAxis;   // 4096
+constexpr int kSortImages = 64;                              // image slots in the key (b % 64)
+constexpr int kSortBins = kSortCells * kSortImages;          // 262144 counters (1 MB)
+
 struct Workspace {
   size_t x_hi, x_lo, h1_hi, h1_lo, h2_hi, h2_lo;     // byte offsets
+  size_t order, keys, bins;                          // point sort: int32 [rows], [rows], [kSortBins]
   size_t total;
 };
 inline size_t workspace_row_bytes(int Kp, int H1, int H2) {
-  return (size_t)2 * 2 * ((size_t)Kp + H1 + H2);
+  return (size_t)2 * 2 * ((size_t)Kp + H1 + H2) + 8;
 }
+inline size_t workspace_fixed_bytes() { return (size_t)kSortBins * 4 + 16 * 256; }
 inline Workspace workspace_layout(int64_t rows, int Kp, int H1, int H2) {
   Workspace w;
   size_t o = 0;
@@ -125,6 +182,8 @@ inline Workspace workspace_layout(int64_t rows, int Kp, int H1, int H2) {
   w.x_hi = take((size_t)rows * Kp * 2); w.x_lo = take((size_t)rows * Kp * 2);
   w.h1_hi = take((size_t)rows * H1 * 2); w.h1_lo = take((size_t)rows * H1 * 2);
   w.h2_hi = take((size_t)rows * H2 * 2); w.h2_lo = take((size_t)rows * H2 * 2);
+  w.order = take((size_t)rows * 4); w.keys = take((size_t)rows * 4);
+  w.bins = take((size_t)kSortBins * 4);
   w.total = o;
   return w;
 }
@@ -139,6 +198,8 @@ struct GatherParams {
   int rows;                   // padded rows (multiple of kRowTile)
   unsigned short* x_hi; unsigned short* x_lo;
   int Kp;
+  int fmt;                    // FMT_BF16_SPLIT or FMT_FP16
+  const int* order;           // row -> chunk-local point index (Morton order), or nullptr
 };
 
 struct GemmParams {
@@ -149,6 +210,8 @@ struct GemmParams {
   unsigned short* out_hi; unsigned short* out_lo; int ldo;   // EPI_RELU_SPLIT
   float* out_f32; int relu;                                  // EPI_F32
   const float* w3; const float* b3; float* sdf; int n_valid; // EPI_RELU_DOT
+  const int* order;                                          // sdf[order[row]] if not null
+  int fmt;                                                   // FMT_BF16_SPLIT or FMT_FP16
 };
 
 enum { EPI_RELU_SPLIT = 0, EPI_F32 = 1, EPI_RELU_DOT = 2 };
@@ -159,8 +222,9 @@ hipError_t launch_prep_img(const ListMap2D maps[LIST_N_IMG_LEVELS], int B, int m
 hipError_t launch_transpose_vox(const ListMap3D& m, int B, float* out, hipStream_t s);
 hipError_t launch_prep_weights(const ListMlpWeights& w, const FeatLayout& L, const PackedMlp& P,
                                char* packed, hipStream_t s);
-hipError_t launch_split(const float* x, unsigned short* hi, unsigned short* lo, int64_t n,
+hipError_t launch_split(const float* x, unsigned short* hi, unsigned short* lo, int64_t n, int fmt,
                         hipStream_t s);
+hipError_t launch_sort_points(const GatherParams& g, int* order, int* keys, int* bins, hipStream_t s);
 hipError_t launch_gather(const GatherParams& g, const FeatLayout& L, const ListQueryArgs& a,
                          hipStream_t s);
 hipError_t launch_features_out(const GatherParams& g, const FeatLayout& L, float* out, int B,

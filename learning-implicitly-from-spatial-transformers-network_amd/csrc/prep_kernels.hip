@@ -58,11 +58,94 @@ __global__ __launch_bounds__(256) void k_prep_img(ListMap2D m, int ms, int Ct, i
   }
 }
 
+// Fast path (W-contiguous source rows, C % G == 0): a workgroup owns one output row y of G channels.
+// It stages the two source rows (y0, y1) of those channels in LDS transposed to [x][c] (global reads
+// coalesced along x), then every thread produces 4 channels of one output pixel from four
+// ds_read_b128 and stores 16 B; consecutive lanes = consecutive channel quads = contiguous stores.
+// Arithmetic and rounding are identical to k_prep_img.
+template <int G>
+__global__ __launch_bounds__(256) void k_prep_img_rows(ListMap2D m, int ms, int Ct, int coff,
+                                                       float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float rows[];     // [2][W][G + 4]
+  constexpr int S = G + 4;
+  const int b = blockIdx.x / ms;
+  const int y = blockIdx.x - b * ms;
+  const int c0 = blockIdx.y * G;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  const float sy = ms > 1 ? (float)(m.H - 1) / (float)(ms - 1) : 0.f;
+  const float sx = ms > 1 ? (float)(m.W - 1) / (float)(ms - 1) : 0.f;
+  const float fy = sy * (float)y;
+  const int y0 = min((int)fy, m.H - 1);
+  const int y1 = y0 + (y0 < m.H - 1 ? 1 : 0);
+  const float wy1 = fy - (float)y0, wy0 = 1.f - wy1;
+  const float* base = m.data + (int64_t)b * m.sb + (int64_t)c0 * m.sc;
+  const bool vec = (m.W % 4) == 0 && (m.sh % 4) == 0 && (m.sc % 4) == 0 && (m.sb % 4) == 0 &&
+                   (reinterpret_cast<uintptr_t>(m.data) & 15) == 0;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const float* srow = base + (int64_t)(r ? y1 : y0) * m.sh;
+    float* drow = rows + r * m.W * S;
+    if (vec) {
+#pragma unroll
+      for (int ci = 0; ci < G / 4; ++ci) {
+        const int c = wave + 4 * ci;
+        for (int x4 = lane; x4 < m.W / 4; x4 += 64) {
+          const float4 t = *(const float4*)(srow + (int64_t)c * m.sc + 4 * x4);
+          float* d = drow + (4 * x4) * S + c;
+          d[0] = t.x; d[S] = t.y; d[2 * S] = t.z; d[3 * S] = t.w;
+        }
+      }
+    } else {
+      for (int c = wave; c < G; c += 4)
+        for (int x = lane; x < m.W; x += 64) drow[x * S + c] = srow[(int64_t)c * m.sc + x];
+    }
+  }
+  __syncthreads();
+  constexpr int Q = G / 4;
+  float* orow = out + ((int64_t)(b * ms + y) * ms) * Ct + coff + c0;
+  for (int idx = threadIdx.x; idx < ms * Q; idx += 256) {
+    const int x = idx / Q, q = idx - x * Q;
+    const float fx = sx * (float)x;
+    const int x0 = min((int)fx, m.W - 1);
+    const int x1 = x0 + (x0 < m.W - 1 ? 1 : 0);
+    const float wx1 = fx - (float)x0, wx0 = 1.f - wx1;
+    const float4 v00 = *(const float4*)(rows + x0 * S + q * 4);
+    const float4 v01 = *(const float4*)(rows + x1 * S + q * 4);
+    const float4 v10 = *(const float4*)(rows + (m.W + x0) * S + q * 4);
+    const float4 v11 = *(const float4*)(rows + (m.W + x1) * S + q * 4);
+    float4 o;
+    o.x = (v00.x * wx0 + v01.x * wx1) * wy0 + (v10.x * wx0 + v11.x * wx1) * wy1;
+    o.y = (v00.y * wx0 + v01.y * wx1) * wy0 + (v10.y * wx0 + v11.y * wx1) * wy1;
+    o.z = (v00.z * wx0 + v01.z * wx1) * wy0 + (v10.z * wx0 + v11.z * wx1) * wy1;
+    o.w = (v00.w * wx0 + v01.w * wx1) * wy0 + (v10.w * wx0 + v11.w * wx1) * wy1;
+    *(float4*)(orow + (int64_t)x * Ct + q * 4) = o;
+  }
+}
+
+template <int G>
+static bool try_prep_img_rows(const ListMap2D& m, int B, int ms, int Ct, int coff, float* out,
+                              hipStream_t s, hipError_t* e) {
+  const size_t lds = (size_t)2 * m.W * (G + 4) * sizeof(float);
+  if (m.sw != 1 || (m.C % G) != 0 || lds > 65536 || (coff % 4) != 0 || (Ct % 4) != 0) return false;
+  hipLaunchKernelGGL(k_prep_img_rows<G>, dim3(B * ms, m.C / G), dim3(256), lds, s, m, ms, Ct, coff, out);
+  *e = hipGetLastError();
+  return true;
+}
+
 hipError_t launch_prep_img(const ListMap2D maps[LIST_N_IMG_LEVELS], int B, int map_size, int Ct,
                            float* out, hipStream_t s) {
   int coff = 0;
   for (int i = 0; i < LIST_N_IMG_LEVELS; ++i) {
     const ListMap2D& m = maps[i];
+    hipError_t fe = hipSuccess;
+    if (try_prep_img_rows<32>(m, B, map_size, Ct, coff, out, s, &fe) ||
+        try_prep_img_rows<16>(m, B, map_size, Ct, coff, out, s, &fe) ||
+        try_prep_img_rows<8>(m, B, map_size, Ct, coff, out, s, &fe)) {
+      if (fe != hipSuccess) return fe;
+      coff += m.C;
+      continue;
+    }
     dim3 grid(B * map_size, (m.C + kResizeCg - 1) / kResizeCg);
     hipLaunchKernelGGL(k_prep_img, grid, dim3(256), 0, s, m, map_size, Ct, coff, out);
     hipError_t e = hipGetLastError();
@@ -103,8 +186,66 @@ __global__ __launch_bounds__(256) void k_transpose_vox(ListMap3D m, int c_begin,
   }
 }
 
+// Fast path (spatially contiguous source, C in {16,32,64,128}): a workgroup moves an 8192-element
+// tile = V voxels x C channels (V = 8192 / C).  16-B global loads along the voxel axis, 16-B global
+// stores along the channel axis (fully contiguous), LDS image [v][c] with the element index XORed by
+// ((v>>2)&7)<<2 (a bijection inside each group of 4 voxels) so that the transposing ds_write_b32
+// pattern spreads over 8 bank groups and the ds_read_b128 of 4 channels stays 16-B aligned.
+template <int C>
+__global__ __launch_bounds__(256) void k_transpose_vox_tile(const float* __restrict__ src, int64_t sb,
+                                                            int64_t sc, int nvox,
+                                                            float* __restrict__ out) {
+  constexpr int V = 8192 / C;          // voxels per tile
+  constexpr int V4 = V / 4;
+  __shared__ __attribute__((aligned(16))) float tile[8192];
+  const int b = blockIdx.y;
+  const int v0 = blockIdx.x * V;
+  const float* in = src + (int64_t)b * sb + v0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = threadIdx.x + 256 * i;
+    const int c = idx / V4, v4 = idx % V4;
+    const float4 t = *(const float4*)(in + (int64_t)c * sc + 4 * v4);
+    const int swz = (v4 & 7) << 2;
+    const int a = (4 * v4) * C + c;
+    tile[(a) ^ swz] = t.x;
+    tile[(a + C) ^ swz] = t.y;
+    tile[(a + 2 * C) ^ swz] = t.z;
+    tile[(a + 3 * C) ^ swz] = t.w;
+  }
+  __syncthreads();
+  float* dst = out + ((int64_t)b * nvox + v0) * C;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = threadIdx.x + 256 * i;            // = v * (C/4) + c4
+    const int v = idx / (C / 4);
+    const int a = idx * 4;                             // v * C + 4 * c4
+    *(float4*)(dst + a) = *(const float4*)(tile + (a ^ (((v >> 2) & 7) << 2)));
+  }
+}
+
+template <int C>
+static hipError_t launch_transpose_tile(const ListMap3D& m, int B, float* out, hipStream_t s) {
+  const int nvox = m.D * m.H * m.W;
+  hipLaunchKernelGGL(k_transpose_vox_tile<C>, dim3(nvox / (8192 / C), B), dim3(256), 0, s, m.data, m.sb,
+                     m.sc, nvox, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_transpose_vox(const ListMap3D& m, int B, float* out, hipStream_t s) {
   const int nvox = m.D * m.H * m.W;
+  const bool spatial_contig = m.sw == 1 && m.sh == m.W && m.sd == (int64_t)m.H * m.W;
+  const bool aligned = (reinterpret_cast<uintptr_t>(m.data) & 15) == 0 && (m.sb % 4) == 0 &&
+                       (m.sc % 4) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+  if (spatial_contig && aligned && (m.C == 16 || m.C == 32 || m.C == 64 || m.C == 128) &&
+      nvox % (8192 / m.C) == 0) {
+    switch (m.C) {
+      case 16: return launch_transpose_tile<16>(m, B, out, s);
+      case 32: return launch_transpose_tile<32>(m, B, out, s);
+      case 64: return launch_transpose_tile<64>(m, B, out, s);
+      default: return launch_transpose_tile<128>(m, B, out, s);
+    }
+  }
   for (int c0 = 0; c0 < m.C; c0 += kTrMaxC) {
     const int nc = m.C - c0 < kTrMaxC ? m.C - c0 : kTrMaxC;
     dim3 grid((nvox + 63) / 64, B);
@@ -119,21 +260,23 @@ hipError_t launch_transpose_vox(const ListMap3D& m, int B, float* out, hipStream
 // MLP parameter repack
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_prep_w0(const float* __restrict__ w0, FeatLayout L, int H1,
-                                                 unsigned short* __restrict__ hi,
+                                                 int fmt, unsigned short* __restrict__ hi,
                                                  unsigned short* __restrict__ lo) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)H1 * L.Kp) return;
   const int n = (int)(i / L.Kp), kp = (int)(i - (int64_t)n * L.Kp);
   const int kr = ref_index_of(L, kp);
   const float v = kr >= 0 ? w0[(int64_t)n * L.F + kr] : 0.f;
+  if (fmt == FMT_FP16) { hi[i] = f2h(v); return; }
   const unsigned short h = f2bf(v);
   hi[i] = h;
   lo[i] = f2bf(v - bf2f(h));
 }
 
 __global__ __launch_bounds__(256) void k_split(const float4* __restrict__ x, uint2* __restrict__ hi,
-                                               uint2* __restrict__ lo, int64_t n4) {
+                                               uint2* __restrict__ lo, int64_t n4, int fmt) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    if (fmt == FMT_FP16) { hi[i] = half4(x[i]); continue; }
     uint2 h, l;
     split4(x[i], h, l);
     hi[i] = h;
@@ -141,29 +284,30 @@ __global__ __launch_bounds__(256) void k_split(const float4* __restrict__ x, uin
   }
 }
 
-hipError_t launch_split(const float* x, unsigned short* hi, unsigned short* lo, int64_t n,
+hipError_t launch_split(const float* x, unsigned short* hi, unsigned short* lo, int64_t n, int fmt,
                         hipStream_t s) {
   const int64_t n4 = n / 4;
   int64_t blocks = (n4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(k_split, dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)x, (uint2*)hi,
-                     (uint2*)lo, n4);
+                     (uint2*)lo, n4, fmt);
   return hipGetLastError();
 }
 
 hipError_t launch_prep_weights(const ListMlpWeights& w, const FeatLayout& L, const PackedMlp& P,
                                char* packed, hipStream_t s) {
   const int64_t n0 = (int64_t)w.H1 * L.Kp;
-  hipLaunchKernelGGL(k_prep_w0, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, s, w.w0, L, w.H1,
+  const int fmt = w.precision == LIST_PREC_FP16 ? FMT_FP16 : FMT_BF16_SPLIT;
+  hipLaunchKernelGGL(k_prep_w0, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, s, w.w0, L, w.H1, fmt,
                      (unsigned short*)(packed + P.w0_hi), (unsigned short*)(packed + P.w0_lo));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   e = launch_split(w.w1, (unsigned short*)(packed + P.w1_hi), (unsigned short*)(packed + P.w1_lo),
-                   (int64_t)w.H2 * w.H1, s);
+                   (int64_t)w.H2 * w.H1, fmt, s);
   if (e != hipSuccess) return e;
   e = launch_split(w.w2, (unsigned short*)(packed + P.w2_hi), (unsigned short*)(packed + P.w2_lo),
-                   (int64_t)w.H3 * w.H2, s);
+                   (int64_t)w.H3 * w.H2, fmt, s);
   if (e != hipSuccess) return e;
   const struct { size_t off; const float* src; size_t n; } cp[] = {
       {P.b0, w.b0, (size_t)w.H1}, {P.b1, w.b1, (size_t)w.H2}, {P.b2, w.b2, (size_t)w.H3},

@@ -17,7 +17,8 @@ N_IMG_LEVELS = 5
 N_VOX_LEVELS = 6
 PREC_BF16X3 = 0
 PREC_BF16 = 1
-PRECISIONS = {"bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
+PREC_FP16 = 2
+PRECISIONS = {"bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "fp16": PREC_FP16}
 
 
 class ListMap2D(C.Structure):
@@ -40,7 +41,7 @@ class ListMlpWeights(C.Structure):
     _fields_ = [("w0", C.c_void_p), ("b0", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p),
                 ("w2", C.c_void_p), ("b2", C.c_void_p), ("w3", C.c_void_p), ("b3", C.c_void_p),
                 ("F", C.c_int32), ("H1", C.c_int32), ("H2", C.c_int32), ("H3", C.c_int32),
-                ("vox_C", C.c_int32 * N_VOX_LEVELS), ("img_C", C.c_int32)]
+                ("vox_C", C.c_int32 * N_VOX_LEVELS), ("img_C", C.c_int32), ("precision", C.c_int32)]
 
 
 class ListQueryArgs(C.Structure):
@@ -58,7 +59,7 @@ class ListQueryArgs(C.Structure):
                 ("sdf", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("precision", C.c_int32),
-                ("stage_events", C.POINTER(C.c_void_p))]
+                ("stage_events", C.POINTER(C.c_void_p)), ("no_sort", C.c_int32)]
 
 
 N_STAGES = 6
@@ -93,6 +94,7 @@ EXPORTS = {
                                C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                C.c_void_p]),
     "list_split_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "list_to_fp16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "list_last_error": (C.c_char_p, []),
     "list_abi_version": (C.c_int, []),
 }
@@ -158,9 +160,9 @@ class PreparedVoxels:
 
 
 class PackedMlp:
-    def __init__(self, data, F, H1, H2, H3, vox_C, img_C):
+    def __init__(self, data, F, H1, H2, H3, vox_C, img_C, fp16):
         self.data, self.F, self.H1, self.H2, self.H3 = data, F, H1, H2, H3
-        self.vox_C, self.img_C = list(vox_C), img_C
+        self.vox_C, self.img_C, self.fp16 = list(vox_C), img_C, fp16
 
 
 def prep_img_maps(img_featuremaps, map_size=137):
@@ -206,7 +208,7 @@ def prep_vox_maps(vox_feat):
     return PreparedVoxels(levels, (pack, list(vox_feat)))
 
 
-def prep_mlp_weights(params, vox_C, img_C=1024):
+def prep_mlp_weights(params, vox_C, img_C=1024, precision="bf16x3"):
     """params: dict with fc_0/fc_1/fc_2/fc_out .weight/.bias (reference state_dict names,
     network/modules.py:196-200).  Conv1d weights may be [out,in,1] or [out,in]."""
     lib = load()
@@ -228,6 +230,7 @@ def prep_mlp_weights(params, vox_C, img_C=1024):
     for i, c in enumerate(vox_C):
         w.vox_C[i] = int(c)
     w.img_C = int(img_C)
+    w.precision = PRECISIONS[precision] if isinstance(precision, str) else int(precision)
     need = lib.list_packed_mlp_bytes(C.byref(w))
     if need == 0:
         raise RuntimeError("list_packed_mlp_bytes failed: "
@@ -239,7 +242,7 @@ def prep_mlp_weights(params, vox_C, img_C=1024):
                "list_prep_mlp_weights")
     # temporaries made by .contiguous() are released stream-ordered by the caching allocator, and
     # every kernel above was enqueued on the same (current) stream: no synchronisation needed
-    return PackedMlp(packed, w.F, w.H1, w.H2, w.H3, vox_C, img_C)
+    return PackedMlp(packed, w.F, w.H1, w.H2, w.H3, vox_C, img_C, w.precision == PREC_FP16)
 
 
 _workspaces = {}
@@ -296,6 +299,9 @@ def _fill_query_args(query, perm, scale, vox, packed, precision, trans_mat=None,
     a.packed_mlp = packed.data.data_ptr()
     a.F, a.H1, a.H2, a.H3 = packed.F, packed.H1, packed.H2, packed.H3
     a.precision = PRECISIONS[precision] if isinstance(precision, str) else int(precision)
+    if (a.precision == PREC_FP16) != bool(packed.fp16):
+        raise RuntimeError("packed MLP weights were prepared for a different precision "
+                           "(fp16 vs bf16 planes); call prep_mlp_weights(..., precision=...) again")
     nbytes = lib.list_query_workspace_bytes(B * N, a.F, a.H1, a.H2, a.H3)
     ws = _workspace(query.device, nbytes)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
@@ -304,12 +310,13 @@ def _fill_query_args(query, perm, scale, vox, packed, precision, trans_mat=None,
 
 
 def sdf_query(query, trans_mat, img, vox, packed, perm=(2, 1, 0), scale=2.0, precision="bf16x3",
-              percep_feat=None, out=None, stage_events=None):
+              percep_feat=None, out=None, stage_events=None, sort_points=True):
     """The fused hot path, network/models.py:91-97 -> sdf [B,N] (float32).
 
     stage_events: optional ctypes array (c_void_p * N_STAGES) of hipEvent_t handles."""
     lib = load()
     a, keep = _fill_query_args(query, perm, scale, vox, packed, precision, trans_mat, img, percep_feat)
+    a.no_sort = 0 if sort_points else 1
     if stage_events is not None:
         a.stage_events = C.cast(stage_events, C.POINTER(C.c_void_p))
     B, N = a.B, a.N
@@ -326,7 +333,8 @@ def gather_features(query, trans_mat, img, vox, packed, perm=(2, 1, 0), scale=2.
                     percep_feat=None):
     """Diagnostic: the concatenated feature tensor of network/modules.py:275, [B,F,N]."""
     lib = load()
-    a, keep = _fill_query_args(query, perm, scale, vox, packed, "bf16x3", trans_mat, img, percep_feat)
+    a, keep = _fill_query_args(query, perm, scale, vox, packed, "fp16" if packed.fp16 else "bf16x3",
+                               trans_mat, img, percep_feat)
     out = torch.zeros((a.B, a.F, a.N), dtype=torch.float32, device=query.device)
     with torch.cuda.device(query.device):
         _check(lib.list_gather_features_fwd(C.byref(a), out.data_ptr(), _stream()),
@@ -366,13 +374,26 @@ def split_bf16(x):
     return hi, lo
 
 
+def to_fp16(x):
+    lib = load()
+    x = _f32_cuda(x, "x").contiguous()
+    out = torch.empty(x.shape, dtype=torch.int16, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib.list_to_fp16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "list_to_fp16")
+    return out
+
+
 def gemm_nt(a, w, bias=None, relu=False, precision="bf16x3"):
     """Diagnostic: out[M,N] = act(a[M,K] @ w[N,K]^T + bias) through the MLP's MFMA kernel."""
     lib = load()
     M, K = a.shape
     N = w.shape[0]
-    a_hi, a_lo = split_bf16(a)
-    w_hi, w_lo = split_bf16(w)
+    if precision == "fp16":
+        a_hi, w_hi = to_fp16(a), to_fp16(w)
+        a_lo, w_lo = a_hi, w_hi
+    else:
+        a_hi, a_lo = split_bf16(a)
+        w_hi, w_lo = split_bf16(w)
     out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     b = _f32_cuda(bias, "bias").contiguous() if bias is not None else None
     with torch.cuda.device(a.device):

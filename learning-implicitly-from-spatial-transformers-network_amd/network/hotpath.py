@@ -118,9 +118,9 @@ def sdf_query(query, trans_mat, img_maps, vox_maps, mlp_params, *, perm=(2, 1, 0
     vox = caches.setdefault("vox", _Cache()).get(
         vox_maps, lambda: hip.prep_vox_maps([v.detach() for v in vox_maps]))
     img_C = img.channels if img is not None else percep_feat.shape[1]
-    packed = caches.setdefault("mlp", _Cache()).get(
+    packed = caches.setdefault("mlp:" + str(precision), _Cache()).get(
         mlp, lambda: hip.prep_mlp_weights({k: t.detach() for k, t in zip(MLP_KEYS, mlp)},
-                                          vox.channels, img_C))
+                                          vox.channels, img_C, precision))
 
     def run():
         return hip.sdf_query(query.detach(), trans_mat.detach() if trans_mat is not None else None,

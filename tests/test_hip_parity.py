@@ -3,6 +3,7 @@ reference produced and against the oracle on identical seeded inputs.
 
 Tolerances (stated):
   * fused SDF, precision bf16x3 (default): max-abs < 1e-4 vs the fp32 reference (observed ~1e-5)
+  * fused SDF, precision fp16            : max-abs < 1e-4 (fp16 operands, fp32 accumulate)
   * fused SDF, precision bf16            : max-abs < 5e-3 (plain bf16 operands)
   * gathered features: 2^-16 relative (values pass through the bf16 hi+lo split) + 2e-5 absolute
   * layout transforms: bit-exact
@@ -18,6 +19,7 @@ from oracle import cases, list_oracle as O, synth
 pytestmark = pytest.mark.gpu
 
 TOL_X3 = 1e-4
+TOL_FP16 = 1e-4          # fp16 operands, fp32 accumulate: measured ~3e-5
 TOL_BF16 = 5e-3
 
 
@@ -33,11 +35,11 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
 
 
-def prepare(hip, c):
+def prepare(hip, c, precision="bf16x3"):
     img = hip.prep_img_maps([dev(m) for m in c["img_maps"]])
     vox = hip.prep_vox_maps([dev(m) for m in c["vox_maps"]])
     packed = hip.prep_mlp_weights({k: dev(v) for k, v in c["weights"].items()},
-                                  vox.channels, img.channels)
+                                  vox.channels, img.channels, precision)
     return img, vox, packed
 
 
@@ -73,6 +75,8 @@ def test_gemm_kernel_matches_fp64(hip, M, N, K):
     np.testing.assert_array_equal(out_r, np.maximum(out, 0))
     out1 = hip.gemm_nt(dev(a), dev(w), dev(b), relu=False, precision="bf16").cpu().numpy()
     assert (np.abs(out1 - ref) / scale).max() < 1e-2
+    out2 = hip.gemm_nt(dev(a), dev(w), dev(b), relu=False, precision="fp16").cpu().numpy()
+    assert (np.abs(out2 - ref) / scale).max() < 1.5e-3
 
 
 def test_gemm_kernel_identity_asymmetric(hip):
@@ -174,6 +178,20 @@ def test_fused_sdf_matches_reference(hip, golden_dir, name):
     err1 = np.abs(sdf1 - g["sdf"]).max()
     print(f"{name}: bf16 max-abs err {err1:.3e}")
     assert err1 < TOL_BF16
+    _, _, packed16 = prepare(hip, c, "fp16")
+    sdf2 = hip.sdf_query(dev(c["query"]), dev(c["trans_mat"]), img, vox, packed16,
+                         precision="fp16").cpu().numpy()
+    err2 = np.abs(sdf2 - g["sdf"]).max()
+    print(f"{name}: fp16 max-abs err {err2:.3e}")
+    assert err2 < TOL_FP16
+    with pytest.raises(RuntimeError, match="different precision"):
+        hip.sdf_query(dev(c["query"]), dev(c["trans_mat"]), img, vox, packed, precision="fp16")
+
+
+def test_fp16_saturates_instead_of_overflowing(hip):
+    x = torch.tensor([1e6, -1e6, 65504.0, 1.0], device="cuda:0")
+    h = hip.to_fp16(x).view(torch.float16).float().cpu().numpy()
+    np.testing.assert_array_equal(h, [65504.0, -65504.0, 65504.0, 1.0])
 
 
 def test_module_level_path_equals_fused(hip, golden_dir):
@@ -270,3 +288,9 @@ def test_full_size_properties(hip, full_case):
     err = np.abs(sdf.cpu().numpy()[:, idx] - ref).max()
     print(f"full-size subset max-abs err {err:.3e}")
     assert err < TOL_X3
+    _, _, packed16 = prepare(hip, c, "fp16")
+    sdf16 = hip.sdf_query(q, T, img, vox, packed16, precision="fp16")
+    err16 = np.abs(sdf16.cpu().numpy()[:, idx] - ref).max()
+    print(f"full-size subset fp16 max-abs err {err16:.3e}; fp16 vs bf16x3 over all points "
+          f"{float((sdf16 - sdf).abs().max()):.3e}")
+    assert err16 < TOL_FP16 and float((sdf16 - sdf).abs().max()) < TOL_FP16
