@@ -46,34 +46,32 @@ __device__ __forceinline__ float4 fma4(const float4& v, float w, const float4& a
   return make_float4(fmaf(v.x, w, a.x), fmaf(v.y, w, a.y), fmaf(v.z, w, a.z), fmaf(v.w, w, a.w));
 }
 
-// One trilinear sample of 4 channels.  base points at (image, channel quad).
-// Accumulation order of the ATen CPU kernel: tnw tne tsw tse bnw bne bsw bse.
-__device__ __forceinline__ float4 trilinear4(const float* __restrict__ base, int C, int H, int W,
-                                             const Axis& ax, const Axis& ay, const Axis& az) {
+// The 8 taps of one trilinear sample: element offsets (relative to the image/channel-quad base) and
+// weights in the accumulation order of the ATen CPU kernel: tnw tne tsw tse bnw bne bsw bse.
+struct Taps { int o[8]; float w[8]; };
+
+__device__ __forceinline__ Taps make_taps(float x, float y, float z, int C, int D, int H, int W) {
+  const Axis ax = axis_setup(x, W), ay = axis_setup(y, H), az = axis_setup(z, D);
   const int o000 = ((az.i0 * H + ay.i0) * W + ax.i0) * C;
   const int sx = ax.has1 ? C : 0;
   const int sy = ay.has1 ? W * C : 0;
   const int sz = az.has1 ? H * W * C : 0;
-  const float4 v000 = *(const float4*)(base + o000);
-  const float4 v001 = *(const float4*)(base + o000 + sx);
-  const float4 v010 = *(const float4*)(base + o000 + sy);
-  const float4 v011 = *(const float4*)(base + o000 + sy + sx);
-  const float4 v100 = *(const float4*)(base + o000 + sz);
-  const float4 v101 = *(const float4*)(base + o000 + sz + sx);
-  const float4 v110 = *(const float4*)(base + o000 + sz + sy);
-  const float4 v111 = *(const float4*)(base + o000 + sz + sy + sx);
-  const float tnw = ax.w0 * ay.w0 * az.w0, tne = ax.w1 * ay.w0 * az.w0;
-  const float tsw = ax.w0 * ay.w1 * az.w0, tse = ax.w1 * ay.w1 * az.w0;
-  const float bnw = ax.w0 * ay.w0 * az.w1, bne = ax.w1 * ay.w0 * az.w1;
-  const float bsw = ax.w0 * ay.w1 * az.w1, bse = ax.w1 * ay.w1 * az.w1;
-  float4 acc = make_float4(v000.x * tnw, v000.y * tnw, v000.z * tnw, v000.w * tnw);
-  acc = fma4(v001, tne, acc);
-  acc = fma4(v010, tsw, acc);
-  acc = fma4(v011, tse, acc);
-  acc = fma4(v100, bnw, acc);
-  acc = fma4(v101, bne, acc);
-  acc = fma4(v110, bsw, acc);
-  acc = fma4(v111, bse, acc);
+  Taps t;
+  t.o[0] = o000;           t.o[1] = o000 + sx;
+  t.o[2] = o000 + sy;      t.o[3] = o000 + sy + sx;
+  t.o[4] = o000 + sz;      t.o[5] = o000 + sz + sx;
+  t.o[6] = o000 + sz + sy; t.o[7] = o000 + sz + sy + sx;
+  t.w[0] = ax.w0 * ay.w0 * az.w0; t.w[1] = ax.w1 * ay.w0 * az.w0;
+  t.w[2] = ax.w0 * ay.w1 * az.w0; t.w[3] = ax.w1 * ay.w1 * az.w0;
+  t.w[4] = ax.w0 * ay.w0 * az.w1; t.w[5] = ax.w1 * ay.w0 * az.w1;
+  t.w[6] = ax.w0 * ay.w1 * az.w1; t.w[7] = ax.w1 * ay.w1 * az.w1;
+  return t;
+}
+
+__device__ __forceinline__ float4 reduce_taps(const float4 (&v)[8], const Taps& t) {
+  float4 acc = make_float4(v[0].x * t.w[0], v[0].y * t.w[0], v[0].z * t.w[0], v[0].w * t.w[0]);
+#pragma unroll
+  for (int k = 1; k < 8; ++k) acc = fma4(v[k], t.w[k], acc);
   return acc;
 }
 
@@ -85,41 +83,62 @@ __device__ __forceinline__ void stencil_point(const Pt& p, float& x, float& y, f
   z = p.z + (J == 5 ? -kDisp : J == 6 ? kDisp : 0.f);
 }
 
-template <int C, int J, int FMT>
-__device__ __forceinline__ void gather_one(const GatherParams& g, const ListVoxLevel& lv,
-                                           const float* __restrict__ base, const Pt& p,
-                                           int64_t out_off) {
-  float x, y, z;
-  stencil_point<J>(p, x, y, z);
-  const Axis ax = axis_setup(x, lv.W), ay = axis_setup(y, lv.H), az = axis_setup(z, lv.D);
-  float4 v = trilinear4(base, C, lv.H, lv.W, ax, ay, az);
-  if (!p.valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
-  store_feat4<FMT>(g.x_hi, g.x_lo, out_off + J * C, v);
+// Two stencil points at a time: all 16 tap loads are issued before the first use, so a wave has
+// 16 KB in flight per step instead of one dependent 8-load round trip per stencil point.
+template <int C, int J0, int J1, int FMT>
+__device__ __forceinline__ void gather_pair(const ListVoxLevel& lv, const float* __restrict__ base,
+                                            const Pt& p, unsigned short* __restrict__ xh,
+                                            unsigned short* __restrict__ xl, int64_t out_off) {
+  float x0, y0, z0, x1, y1, z1;
+  stencil_point<J0>(p, x0, y0, z0);
+  stencil_point<J1>(p, x1, y1, z1);
+  const Taps t0 = make_taps(x0, y0, z0, C, lv.D, lv.H, lv.W);
+  const Taps t1 = make_taps(x1, y1, z1, C, lv.D, lv.H, lv.W);
+  float4 v0[8], v1[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v0[k] = *(const float4*)(base + t0.o[k]);
+  if (J1 != J0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v1[k] = *(const float4*)(base + t1.o[k]);
+  }
+  float4 r0 = reduce_taps(v0, t0);
+  if (!p.valid) r0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  store_feat4<FMT>(xh, xl, out_off + J0 * C, r0);
+  if (J1 != J0) {
+    float4 r1 = reduce_taps(v1, t1);
+    if (!p.valid) r1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    store_feat4<FMT>(xh, xl, out_off + J1 * C, r1);
+  }
 }
 
-// grid = rows/64, block = 256.  LP = C/4 lanes share a point; a wave covers 64/LP points.
+// grid = rows/RB, block = 256.  LP = C/4 lanes share a point; a wave covers 64/LP points.  The
+// workgroup's points are fetched once, in parallel, into LDS (one dependent chain order -> query
+// per workgroup instead of one per iteration).
 template <int C, int FMT>
 __global__ __launch_bounds__(256) void k_gather_vox(GatherParams g, ListVoxLevel lv, int col_off) {
   constexpr int LP = C / 4;              // lanes per point
   constexpr int PW = 64 / LP;            // points per wave per iteration
   constexpr int ITERS = (4 * PW >= kGatherRows) ? 1 : kGatherRows / (4 * PW);
   constexpr int RB = 4 * PW * ITERS;     // rows per workgroup (64, 128 or 256: divides g.rows)
+  __shared__ Pt pts[RB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int quad = lane % LP, psub = lane / LP;
   const int blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  if (threadIdx.x < RB) pts[threadIdx.x] = load_point(g, blk * RB + threadIdx.x);
+  __syncthreads();
+  unsigned short* __restrict__ xh = g.x_hi;
+  unsigned short* __restrict__ xl = g.x_lo;
 #pragma unroll 1
   for (int it = 0; it < ITERS; ++it) {
-    const int row = blk * RB + it * (4 * PW) + wave * PW + psub;
-    const Pt p = load_point(g, row);
-    const float* base = lv.data + (int64_t)p.b * lv.image_stride + quad * 4;
+    const int local = it * (4 * PW) + wave * PW + psub;
+    const int row = blk * RB + local;
+    const Pt p = pts[local];
+    const float* __restrict__ base = lv.data + (int64_t)p.b * lv.image_stride + quad * 4;
     const int64_t out_off = (int64_t)row * g.Kp + col_off + quad * 4;
-    gather_one<C, 0, FMT>(g, lv, base, p, out_off);
-    gather_one<C, 1, FMT>(g, lv, base, p, out_off);
-    gather_one<C, 2, FMT>(g, lv, base, p, out_off);
-    gather_one<C, 3, FMT>(g, lv, base, p, out_off);
-    gather_one<C, 4, FMT>(g, lv, base, p, out_off);
-    gather_one<C, 5, FMT>(g, lv, base, p, out_off);
-    gather_one<C, 6, FMT>(g, lv, base, p, out_off);
+    gather_pair<C, 0, 1, FMT>(lv, base, p, xh, xl, out_off);
+    gather_pair<C, 2, 3, FMT>(lv, base, p, xh, xl, out_off);
+    gather_pair<C, 4, 5, FMT>(lv, base, p, xh, xl, out_off);
+    gather_pair<C, 6, 6, FMT>(lv, base, p, xh, xl, out_off);
   }
 }
 
@@ -169,23 +188,192 @@ __device__ __forceinline__ float4 bilinear4(const float* __restrict__ img, const
   return acc;
 }
 
-// grid = rows/64, block = 256: the block walks its 64 points, lanes over channel quads.
+// ---- ordering of the query points ---------------------------------------------------------------------
+// Random query points make every tap a cold line.  Rows are therefore processed in (image, Morton
+// cell) order, a counting sort on key = image_slot * 4096 + morton(16^3 cell): consecutive rows (and
+// so the workgroups resident at any moment on an XCD, see xcd_contiguous_block) sample one small
+// region of the voxel maps.  The 2-D gather walks the points in a second order, (image, pixel row,
+// pixel column / 4) of their projection, and writes through row_of[] into the same X rows.
+// Results are independent of either order bit for bit (every point is computed on its own); the
+// order inside a bin comes from atomics and is not deterministic.
+__device__ __forceinline__ unsigned spread3(unsigned v) {      // 4 bits -> every third bit
+  v = (v | (v << 4)) & 0x0C3u;
+  v = (v | (v << 2)) & 0x249u;
+  return v;
+}
+
+struct SortParams { int b_first; int pixel; const float* trans_mat; int ms; float clamp_hi; };
+
+__device__ __forceinline__ int sort_key(const GatherParams& g, const SortParams& sp, int i) {
+  const int64_t gp = g.p_begin + i;
+  const int b = (int)(gp / g.N);
+  const int n = (int)(gp - (int64_t)b * g.N);
+  const float* q = g.query + (int64_t)b * g.q_sb + (int64_t)n * g.q_sn;
+  const float px = q[(int64_t)g.perm0 * g.q_sc] * g.scale;
+  const float py = q[(int64_t)g.perm1 * g.q_sc] * g.scale;
+  const float pz = q[(int64_t)g.perm2 * g.q_sc] * g.scale;
+  const int slot = (b - sp.b_first) % kSortImages;
+  if (sp.pixel) {
+    const Proj pr = project(sp.trans_mat + b * 12, px, py, pz, sp.ms, 1, sp.clamp_hi);
+    const int pix = pr.o00;                               // y0 * ms + x0 (Ct = 1)
+    const int y0 = pix / sp.ms, x0 = pix - y0 * sp.ms;
+    const int cell = min(y0 * ((sp.ms + 3) / 4) + (x0 >> 2), kSortPixCells - 1);
+    return slot * kSortPixCells + cell;
+  }
+  const float pc[3] = {px, py, pz};
+  unsigned c[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float v = (pc[a] + 1.f) * (0.5f * kSortCellsPerAxis);
+    c[a] = (unsigned)fminf(fmaxf(v, 0.f), (float)(kSortCellsPerAxis - 1));
+  }
+  const unsigned m = spread3(c[0]) | (spread3(c[1]) << 1) | (spread3(c[2]) << 2);
+  return slot * kSortCells + (int)m;
+}
+
+__global__ __launch_bounds__(256) void k_sort_hist(GatherParams g, SortParams sp, int* __restrict__ keys,
+                                                   int* __restrict__ bins) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.n_valid) return;
+  const int k = sort_key(g, sp, i);
+  keys[i] = k;
+  atomicAdd(&bins[k], 1);
+}
+
+// Exclusive scan of the counters, one workgroup per image slot.  The number of points of every
+// slot is known on the host (points per image is fixed), so each slot's base offset arrives as an
+// argument and the slots scan independently: `cells` (4096 or 8192) counters, 1024 threads.
+struct SlotBase { int base[kSortImages]; };
+
+__global__ __launch_bounds__(1024) void k_sort_scan(int* __restrict__ bins, int cells, SlotBase sb) {
+  __shared__ int part[1024];
+  const int per = cells / 1024;                        // 4 or 8 consecutive counters per thread
+  int* mine = bins + (int64_t)blockIdx.x * cells + threadIdx.x * per;
+  int c[8];
+  int sum = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { c[i] = i < per ? mine[i] : 0; sum += c[i]; }
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = sb.base[blockIdx.x] + part[threadIdx.x] - sum;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i < per) { mine[i] = run; run += c[i]; }
+}
+
+// order[pos] = i and, if wanted, inverse[i] = pos
+__global__ __launch_bounds__(256) void k_sort_scatter(int n_valid, const int* __restrict__ keys,
+                                                      int* __restrict__ bins, int* __restrict__ order,
+                                                      int* __restrict__ inverse) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_valid) return;
+  const int pos = atomicAdd(&bins[keys[i]], 1);
+  order[pos] = i;
+  if (inverse) inverse[i] = pos;
+}
+
+static hipError_t sort_pass(const GatherParams& g, const SortParams& sp, int cells, int* keys, int* bins,
+                            int* order, int* inverse, hipStream_t s) {
+  const int64_t b_last = (g.p_begin + g.n_valid - 1) / g.N;
+  const int nslots = (int)((b_last - sp.b_first + 1 < kSortImages) ? (b_last - sp.b_first + 1) : kSortImages);
+  const int nbins = nslots * cells;
+  hipError_t e = hipMemsetAsync(bins, 0, (size_t)nbins * sizeof(int), s);
+  if (e != hipSuccess) return e;
+  const unsigned nb = (unsigned)((g.n_valid + 255) / 256);
+  GatherParams raw = g;
+  raw.order = nullptr;
+  // points per slot: image b of the chunk goes to slot (b - b_first) % kSortImages
+  SlotBase sb;
+  int cnt[kSortImages] = {0};
+  const int64_t p_end = g.p_begin + g.n_valid;
+  for (int64_t b = sp.b_first; b <= b_last; ++b) {
+    const int64_t lo = b * g.N > g.p_begin ? b * g.N : g.p_begin;
+    const int64_t hi = (b + 1) * g.N < p_end ? (b + 1) * g.N : p_end;
+    cnt[(b - sp.b_first) % kSortImages] += (int)(hi - lo);
+  }
+  int run = 0;
+  for (int i = 0; i < kSortImages; ++i) { sb.base[i] = run; run += cnt[i]; }
+  hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(256), 0, s, raw, sp, keys, bins);
+  hipLaunchKernelGGL(k_sort_scan, dim3(nslots), dim3(1024), 0, s, bins, cells, sb);
+  hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(256), 0, s, g.n_valid, keys, bins, order, inverse);
+  return hipGetLastError();
+}
+
+hipError_t launch_sort_points(const GatherParams& g, const ListQueryArgs& a, const SortBuffers& sb,
+                              hipStream_t s) {
+  SortParams sp;
+  sp.b_first = (int)(g.p_begin / g.N);
+  sp.pixel = 0; sp.trans_mat = nullptr; sp.ms = 0; sp.clamp_hi = 0.f;
+  const bool img = a.percep_feat == nullptr && sb.order_img != nullptr &&
+                   a.map_size * ((a.map_size + 3) / 4) <= kSortPixCells;
+  hipError_t e = sort_pass(g, sp, kSortCells, sb.keys, sb.bins, sb.order, img ? sb.row_of : nullptr, s);
+  if (e != hipSuccess || !img) return e;
+  sp.pixel = 1; sp.trans_mat = a.trans_mat; sp.ms = a.map_size; sp.clamp_hi = a.clamp_hi;
+  return sort_pass(g, sp, kSortPixCells, sb.keys, sb.bins, sb.order_img, nullptr, s);
+}
+
+// grid = rows/64, block = 256: the workgroup walks its 64 points, lanes over channel quads.  The 64
+// projections are computed once, in parallel, by the first wave (one dependent chain order -> query
+// -> trans_mat per workgroup), then two points (8 x 16-B loads per lane) are in flight per step.
+struct ImgPoint { Proj pr; int row; int b; int valid; };
+
 template <int FMT>
 __global__ __launch_bounds__(256) void k_gather_img(GatherParams g, const float* __restrict__ img_map,
                                                     const float* __restrict__ trans_mat, int ms,
                                                     int Ct, float clamp_hi, int col_off) {
+  __shared__ ImgPoint ipt[kGatherRows];
   const int nq = Ct / 4;
   const int blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
-#pragma unroll 2
-  for (int i = 0; i < kGatherRows; ++i) {
-    const int row = blk * kGatherRows + i;
-    const Pt p = load_point(g, row);
-    const Proj pr = project(trans_mat + p.b * 12, p.x, p.y, p.z, ms, Ct, clamp_hi);
-    const float* img = img_map + (int64_t)p.b * ms * ms * Ct;
+  if (threadIdx.x < kGatherRows) {
+    int row = blk * kGatherRows + threadIdx.x;
+    Pt p;
+    if (g.order_img) {          // slot -> point (pixel order) -> X row
+      p.valid = row < g.n_valid;
+      const int pt = p.valid ? g.order_img[row] : 0;
+      const int64_t gp = g.p_begin + pt;
+      p.b = (int)(gp / g.N);
+      const int n = (int)(gp - (int64_t)p.b * g.N);
+      const float* q = g.query + (int64_t)p.b * g.q_sb + (int64_t)n * g.q_sn;
+      p.x = q[(int64_t)g.perm0 * g.q_sc] * g.scale;
+      p.y = q[(int64_t)g.perm1 * g.q_sc] * g.scale;
+      p.z = q[(int64_t)g.perm2 * g.q_sc] * g.scale;
+      if (p.valid) row = g.row_of[pt];
+    } else {
+      p = load_point(g, row);
+    }
+    ImgPoint ip;
+    ip.pr = project(trans_mat + p.b * 12, p.x, p.y, p.z, ms, Ct, clamp_hi);
+    ip.row = row; ip.b = p.b; ip.valid = p.valid ? 1 : 0;
+    ipt[threadIdx.x] = ip;
+  }
+  __syncthreads();
+  unsigned short* __restrict__ xh = g.x_hi;
+  unsigned short* __restrict__ xl = g.x_lo;
+  const int64_t img_stride = (int64_t)ms * ms * Ct;
+#pragma unroll 1
+  for (int i = 0; i < kGatherRows; i += 2) {
+    const ImgPoint a = ipt[i], c = ipt[i + 1];
+    const float* __restrict__ ia = img_map + a.b * img_stride;
+    const float* __restrict__ ic = img_map + c.b * img_stride;
     for (int q = threadIdx.x; q < nq; q += 256) {
-      float4 v = bilinear4(img + q * 4, pr);
-      if (!p.valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      store_feat4<FMT>(g.x_hi, g.x_lo, (int64_t)row * g.Kp + col_off + q * 4, v);
+      const float4 a00 = *(const float4*)(ia + a.pr.o00 + q * 4), a01 = *(const float4*)(ia + a.pr.o01 + q * 4);
+      const float4 a10 = *(const float4*)(ia + a.pr.o10 + q * 4), a11 = *(const float4*)(ia + a.pr.o11 + q * 4);
+      const float4 c00 = *(const float4*)(ic + c.pr.o00 + q * 4), c01 = *(const float4*)(ic + c.pr.o01 + q * 4);
+      const float4 c10 = *(const float4*)(ic + c.pr.o10 + q * 4), c11 = *(const float4*)(ic + c.pr.o11 + q * 4);
+      float4 ra = make_float4(a00.x * a.pr.w00, a00.y * a.pr.w00, a00.z * a.pr.w00, a00.w * a.pr.w00);
+      ra = fma4(a01, a.pr.w01, ra); ra = fma4(a10, a.pr.w10, ra); ra = fma4(a11, a.pr.w11, ra);
+      float4 rc = make_float4(c00.x * c.pr.w00, c00.y * c.pr.w00, c00.z * c.pr.w00, c00.w * c.pr.w00);
+      rc = fma4(c01, c.pr.w01, rc); rc = fma4(c10, c.pr.w10, rc); rc = fma4(c11, c.pr.w11, rc);
+      if (!a.valid) ra = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!c.valid) rc = make_float4(0.f, 0.f, 0.f, 0.f);
+      store_feat4<FMT>(xh, xl, (int64_t)a.row * g.Kp + col_off + q * 4, ra);
+      store_feat4<FMT>(xh, xl, (int64_t)c.row * g.Kp + col_off + q * 4, rc);
     }
   }
 }
@@ -214,18 +402,11 @@ __global__ __launch_bounds__(256) void k_copy_percep(GatherParams g, const float
 // ---- tail: scalar voxel levels, xyz, zero padding -----------------------------------------------
 struct TailLevels { ListVoxLevel lv[LIST_N_VOX_LEVELS]; int off[LIST_N_VOX_LEVELS]; int n; };
 
-__device__ __forceinline__ float trilinear1(const float* __restrict__ base, int H, int W,
-                                            const Axis& ax, const Axis& ay, const Axis& az) {
-  const int o = (az.i0 * H + ay.i0) * W + ax.i0;
-  const int sx = ax.has1 ? 1 : 0, sy = ay.has1 ? W : 0, sz = az.has1 ? H * W : 0;
-  float acc = base[o] * (ax.w0 * ay.w0 * az.w0);
-  acc = fmaf(base[o + sx], ax.w1 * ay.w0 * az.w0, acc);
-  acc = fmaf(base[o + sy], ax.w0 * ay.w1 * az.w0, acc);
-  acc = fmaf(base[o + sy + sx], ax.w1 * ay.w1 * az.w0, acc);
-  acc = fmaf(base[o + sz], ax.w0 * ay.w0 * az.w1, acc);
-  acc = fmaf(base[o + sz + sx], ax.w1 * ay.w0 * az.w1, acc);
-  acc = fmaf(base[o + sz + sy], ax.w0 * ay.w1 * az.w1, acc);
-  acc = fmaf(base[o + sz + sy + sx], ax.w1 * ay.w1 * az.w1, acc);
+// 8 scalar taps of one trilinear sample (C == 1)
+__device__ __forceinline__ float reduce_taps1(const float (&v)[8], const Taps& t) {
+  float acc = v[0] * t.w[0];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) acc = fmaf(v[k], t.w[k], acc);
   return acc;
 }
 
@@ -243,16 +424,21 @@ __global__ __launch_bounds__(256) void k_gather_tail(GatherParams g, TailLevels 
   const int64_t ro = (int64_t)row * g.Kp;
   for (int l = 0; l < tl.n; ++l) {
     const ListVoxLevel& lv = tl.lv[l];
-    const float* base = lv.data + (int64_t)p.b * lv.image_stride;
+    const float* __restrict__ base = lv.data + (int64_t)p.b * lv.image_stride;
+    Taps t[LIST_N_STENCIL];
+    float v[LIST_N_STENCIL][8];
 #pragma unroll
     for (int j = 0; j < LIST_N_STENCIL; ++j) {
       const float x = p.x + (j == 1 ? -kDisp : j == 2 ? kDisp : 0.f);
       const float y = p.y + (j == 3 ? -kDisp : j == 4 ? kDisp : 0.f);
       const float z = p.z + (j == 5 ? -kDisp : j == 6 ? kDisp : 0.f);
-      const Axis ax = axis_setup(x, lv.W), ay = axis_setup(y, lv.H), az = axis_setup(z, lv.D);
-      const float v = trilinear1(base, lv.H, lv.W, ax, ay, az);
-      put<FMT>(g, ro + tl.off[l] + j, p.valid ? v : 0.f);
+      t[j] = make_taps(x, y, z, 1, lv.D, lv.H, lv.W);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[j][k] = base[t[j].o[k]];       // all 56 loads before any use
     }
+#pragma unroll
+    for (int j = 0; j < LIST_N_STENCIL; ++j)
+      put<FMT>(g, ro + tl.off[l] + j, p.valid ? reduce_taps1(v[j], t[j]) : 0.f);
   }
   put<FMT>(g, ro + xyz_off + 0, p.valid ? p.x : 0.f);     // p_features, modules.py:257
   put<FMT>(g, ro + xyz_off + 1, p.valid ? p.y : 0.f);
@@ -261,84 +447,6 @@ __global__ __launch_bounds__(256) void k_gather_tail(GatherParams g, TailLevels 
     g.x_hi[ro + k] = 0;
     if (FMT == FMT_BF16_SPLIT) g.x_lo[ro + k] = 0;
   }
-}
-
-// ---- Morton ordering of the query points -------------------------------------------------------------
-// Random query points make every tap a cold line.  Rows are therefore processed in (image, Morton
-// cell) order, a counting sort on key = (b % 64) * 4096 + morton(16^3 cell): consecutive rows (and so
-// the workgroups resident at any moment, on every XCD) sample one small region of the maps, which
-// turns most taps into L1/L2 hits.  Results are independent of the row order bit for bit (every row
-// is computed on its own); the order inside a cell comes from atomics and is not deterministic.
-__device__ __forceinline__ unsigned spread3(unsigned v) {      // 4 bits -> every third bit
-  v = (v | (v << 4)) & 0x0C3u;
-  v = (v | (v << 2)) & 0x249u;
-  return v;
-}
-__device__ __forceinline__ int sort_key(const GatherParams& g, int i, int b_first) {
-  const int64_t gp = g.p_begin + i;
-  const int b = (int)(gp / g.N);
-  const int n = (int)(gp - (int64_t)b * g.N);
-  const float* q = g.query + (int64_t)b * g.q_sb + (int64_t)n * g.q_sn;
-  unsigned c[3];
-  const int perm[3] = {g.perm0, g.perm1, g.perm2};
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const float v = (q[(int64_t)perm[a] * g.q_sc] * g.scale + 1.f) * (0.5f * kSortCellsPerAxis);
-    c[a] = (unsigned)fminf(fmaxf(v, 0.f), (float)(kSortCellsPerAxis - 1));
-  }
-  const unsigned m = spread3(c[0]) | (spread3(c[1]) << 1) | (spread3(c[2]) << 2);
-  return ((b - b_first) % kSortImages) * kSortCells + (int)m;
-}
-
-__global__ __launch_bounds__(256) void k_sort_hist(GatherParams g, int b_first, int* __restrict__ keys,
-                                                   int* __restrict__ bins) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= g.n_valid) return;
-  const int k = sort_key(g, i, b_first);
-  keys[i] = k;
-  atomicAdd(&bins[k], 1);
-}
-
-// exclusive scan of nbins (a multiple of 4096) counters by ONE workgroup of 1024 threads
-__global__ __launch_bounds__(1024) void k_sort_scan(int* __restrict__ bins, int nbins) {
-  __shared__ int part[1024];
-  const int PER = nbins / 1024;
-  int* mine = bins + threadIdx.x * PER;
-  int sum = 0;
-  for (int i = 0; i < PER; ++i) sum += mine[i];
-  part[threadIdx.x] = sum;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    const int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-    __syncthreads();
-    part[threadIdx.x] += v;
-    __syncthreads();
-  }
-  int run = part[threadIdx.x] - sum;
-  for (int i = 0; i < PER; ++i) { const int c = mine[i]; mine[i] = run; run += c; }
-}
-
-__global__ __launch_bounds__(256) void k_sort_scatter(int n_valid, const int* __restrict__ keys,
-                                                      int* __restrict__ bins, int* __restrict__ order) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_valid) return;
-  order[atomicAdd(&bins[keys[i]], 1)] = i;
-}
-
-hipError_t launch_sort_points(const GatherParams& g, int* order, int* keys, int* bins, hipStream_t s) {
-  const int b_first = (int)(g.p_begin / g.N);
-  const int64_t b_last = (g.p_begin + g.n_valid - 1) / g.N;
-  const int nslots = (int)((b_last - b_first + 1 < kSortImages) ? (b_last - b_first + 1) : kSortImages);
-  const int nbins = nslots * kSortCells;
-  hipError_t e = hipMemsetAsync(bins, 0, (size_t)nbins * sizeof(int), s);
-  if (e != hipSuccess) return e;
-  const unsigned nb = (unsigned)((g.n_valid + 255) / 256);
-  GatherParams raw = g;
-  raw.order = nullptr;
-  hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(256), 0, s, raw, b_first, keys, bins);
-  hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, s, bins, nbins);
-  hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(256), 0, s, g.n_valid, keys, bins, order);
-  return hipGetLastError();
 }
 
 // ---- launch ----------------------------------------------------------------------------------------

@@ -82,7 +82,7 @@ GatherParams make_gather(const ListQueryArgs* a, const FeatLayout& L, const Work
   g.x_lo = (unsigned short*)((char*)a->workspace + ws.x_lo);
   g.Kp = L.Kp;
   g.fmt = a->precision == LIST_PREC_FP16 ? FMT_FP16 : FMT_BF16_SPLIT;
-  g.order = nullptr;
+  g.order = nullptr; g.order_img = nullptr; g.row_of = nullptr;
   return g;
 }
 
@@ -255,10 +255,15 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
     mark(LIST_STAGE_BEGIN);
     hipError_t e = hipSuccess;
     if (!a->no_sort) {
-      int* order = (int*)(wsb + ws.order);
-      e = launch_sort_points(g, order, (int*)(wsb + ws.keys), (int*)(wsb + ws.bins), s);
+      SortBuffers sb;
+      sb.order = (int*)(wsb + ws.order); sb.order_img = (int*)(wsb + ws.order_img);
+      sb.row_of = (int*)(wsb + ws.row_of); sb.keys = (int*)(wsb + ws.keys); sb.bins = (int*)(wsb + ws.bins);
+      e = launch_sort_points(g, *a, sb, s);
       if (e != hipSuccess) return hip_fail(e, "sort launch");
-      g.order = order;
+      g.order = sb.order;
+      if (a->percep_feat == nullptr && a->map_size * ((a->map_size + 3) / 4) <= kSortPixCells) {
+        g.order_img = sb.order_img; g.row_of = sb.row_of;
+      }
     }
     e = launch_gather(g, L, *a, s);
     if (e != hipSuccess) return hip_fail(e, "gather launch");

@@ -164,15 +164,17 @@ inline PackedMlp packed_mlp_layout(int Kp, int H1, int H2, int H3) {
 constexpr int kSortCellsPerAxis = 16;                        // Morton cells per axis per image
 constexpr int kSortCells = kSortCellsPerAxis * kSortCellsPerAxis * kSortCellsPerAxis;   // 4096
 constexpr int kSortImages = 64;                              // image slots in the key (b % 64)
-constexpr int kSortBins = kSortCells * kSortImages;          // 262144 counters (1 MB)
+constexpr int kSortPixCells = 8192;                          // pixel-order bins per image (>= ms * ceil(ms/4))
+constexpr int kSortBins = kSortPixCells * kSortImages;       // 524288 counters (2 MB)
 
 struct Workspace {
   size_t x_hi, x_lo, h1_hi, h1_lo, h2_hi, h2_lo;     // byte offsets
   size_t order, keys, bins;                          // point sort: int32 [rows], [rows], [kSortBins]
+  size_t order_img, row_of;                          // pixel order for the 2-D gather; point -> X row
   size_t total;
 };
 inline size_t workspace_row_bytes(int Kp, int H1, int H2) {
-  return (size_t)2 * 2 * ((size_t)Kp + H1 + H2) + 8;
+  return (size_t)2 * 2 * ((size_t)Kp + H1 + H2) + 16;
 }
 inline size_t workspace_fixed_bytes() { return (size_t)kSortBins * 4 + 16 * 256; }
 inline Workspace workspace_layout(int64_t rows, int Kp, int H1, int H2) {
@@ -183,6 +185,7 @@ inline Workspace workspace_layout(int64_t rows, int Kp, int H1, int H2) {
   w.h1_hi = take((size_t)rows * H1 * 2); w.h1_lo = take((size_t)rows * H1 * 2);
   w.h2_hi = take((size_t)rows * H2 * 2); w.h2_lo = take((size_t)rows * H2 * 2);
   w.order = take((size_t)rows * 4); w.keys = take((size_t)rows * 4);
+  w.order_img = take((size_t)rows * 4); w.row_of = take((size_t)rows * 4);
   w.bins = take((size_t)kSortBins * 4);
   w.total = o;
   return w;
@@ -200,6 +203,8 @@ struct GatherParams {
   int Kp;
   int fmt;                    // FMT_BF16_SPLIT or FMT_FP16
   const int* order;           // row -> chunk-local point index (Morton order), or nullptr
+  const int* order_img;       // 2-D gather: slot -> chunk-local point index (pixel order), or nullptr
+  const int* row_of;          // chunk-local point index -> X row (inverse of `order`)
 };
 
 struct GemmParams {
@@ -224,7 +229,9 @@ hipError_t launch_prep_weights(const ListMlpWeights& w, const FeatLayout& L, con
                                char* packed, hipStream_t s);
 hipError_t launch_split(const float* x, unsigned short* hi, unsigned short* lo, int64_t n, int fmt,
                         hipStream_t s);
-hipError_t launch_sort_points(const GatherParams& g, int* order, int* keys, int* bins, hipStream_t s);
+struct SortBuffers { int* order; int* order_img; int* row_of; int* keys; int* bins; };
+hipError_t launch_sort_points(const GatherParams& g, const ListQueryArgs& a, const SortBuffers& sb,
+                              hipStream_t s);
 hipError_t launch_gather(const GatherParams& g, const FeatLayout& L, const ListQueryArgs& a,
                          hipStream_t s);
 hipError_t launch_features_out(const GatherParams& g, const FeatLayout& L, float* out, int B,
