@@ -87,13 +87,122 @@ def make_inputs(workload, rank, device):
                 weights=weights, map_size=map_size, clamp_hi=clamp_hi)
 
 
+# Algorithmic work per query point of every kernel (bytes for the HBM-bound gathers and
+# layout kernels at s = 4 B per map element, FLOPs for the MFMA kernels).  B_IMG etc. per step.
+VOX_C = [1, 16, 32, 64, 128, 128]
+
+
+def kernel_table(B, N, img_res, vox_res, map_size, x_bytes_per_feature):
+    """name -> (bound, algorithmic units per step)."""
+    P = B * N
+    from oracle import synth
+    vox_elems = [int(np.prod(s)) for s in synth.vox_map_shapes(B, vox_res)]
+    img_elems_in = sum(int(np.prod(s)) for s in synth.img_map_shapes(B, img_res))
+    img_elems_out = B * map_size * map_size * 1024
+    t = {
+        "prep_img_resize_nhwc": ("hbm", 4 * (img_elems_in + img_elems_out)),
+        "prep_vox_ndhwc": ("hbm", 8 * sum(vox_elems[1:])),
+        "gather_img": ("hbm", P * (4 * 1024 * 4 + 1024 * x_bytes_per_feature + 12)),
+        "gather_tail": ("hbm", P * (7 * 8 * 4 + 48 * x_bytes_per_feature)),
+        "fc_0": ("mfma", P * 2 * 3610 * 512),
+        "fc_1": ("mfma", P * 2 * 512 * 256),
+        "fc_2_out": ("mfma", P * 2 * (256 * 256 + 256)),
+    }
+    for i, c in enumerate(VOX_C[1:], 1):
+        t[f"gather_vox_l{i}"] = ("hbm", P * (7 * 8 * c * 4 + 7 * c * x_bytes_per_feature))
+    return t
+
+
+def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gather_fn):
+    import torch.distributed as dist
+    B, N = inp["B"], inp["N"]
+    n_ev = hip.N_STAGES
+    step_events = []
+    for _ in range(steps):
+        pre = [ev.create() for _ in range(4)]
+        arr = (ctypes.c_void_p * n_ev)(*[ev.create() for _ in range(n_ev)])
+        step_events.append((pre, arr))
+    gathered = torch.empty((world * B, N), dtype=torch.float32, device=device) if world > 1 else None
+    sdf = torch.empty((B, N), dtype=torch.float32, device=device)
+
+    def step(events=None):
+        pre, arr = events if events else (None, None)
+        if pre: ev.record(pre[0])
+        img = hip.prep_img_maps(inp["img_maps"], inp["map_size"])
+        if pre: ev.record(pre[1])
+        vox = hip.prep_vox_maps(inp["vox_maps"])
+        if pre: ev.record(pre[2])
+        packed = hip.prep_mlp_weights(inp["weights"], vox.channels, img.channels, precision)
+        if pre: ev.record(pre[3])
+        hip.sdf_query(inp["query"], inp["trans_mat"], img, vox, packed, precision=precision,
+                      out=sdf, stage_events=arr)
+        if world > 1:
+            gather_fn(sdf, out=gathered)
+        return sdf
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(step_events[i])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    names = ["prep_img_resize_nhwc", "prep_vox_ndhwc", "prep_weights"] + list(hip.STAGE_NAMES)
+    acc = np.zeros(len(names))
+    for pre, arr in step_events:
+        acc[0] += ev.elapsed_ms(pre[0], pre[1])
+        acc[1] += ev.elapsed_ms(pre[1], pre[2])
+        acc[2] += ev.elapsed_ms(pre[2], pre[3])
+        for s in range(n_ev - 1):
+            acc[3 + s] += ev.elapsed_ms(ctypes.c_void_p(arr[s]), ctypes.c_void_p(arr[s + 1]))
+    kernel_ms = dict(zip(names, (acc / steps).tolist()))
+    return elapsed, kernel_ms, sdf
+
+
+def roofline_of(kernel_ms, table, precision):
+    """Roofline entry of the longest single kernel launch."""
+    # candidates are single kernel launches; the two prep entries are groups of up to five launches
+    single = [k for k in table if not k.startswith("prep_")]
+    dom = max(single, key=lambda k: kernel_ms.get(k, 0.0))
+    bound, units = table[dom]
+    secs = kernel_ms[dom] * 1e-3
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tf):
+        traffic = json.load(open(tf)).get(precision, {}).get(dom)
+    if bound == "mfma":
+        ach = units / secs / 1e12
+        return {"kernel": {"fc_0": "k_gemm_nt (fc_0 + ReLU)", "fc_1": "k_gemm_nt (fc_1 + ReLU)",
+                           "fc_2_out": "k_gemm_nt (fc_2 + ReLU + fc_out)"}[dom],
+                "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "launch_ms": kernel_ms[dom],
+                "algorithmic_flop_per_launch": units,
+                "mfma_products_per_mac": 3 if precision == "bf16x3" else 1}
+    ach = units / secs / 1e9
+    return {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": ach / PEAK_HBM_GBS, "traffic": traffic, "launch_ms": kernel_ms[dom],
+            "algorithmic_bytes_per_launch": units}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="list_im2sdf_b8_n20k_224", choices=sorted(WORKLOADS))
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp16", "bf16"])
+    ap.add_argument("--precision", default=None, choices=["fp16", "bf16x3", "bf16"],
+                    help="MLP arithmetic; default: headline fp16 plus a shorter bf16x3 run reported under 'alt'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-images", type=int, default=2)
     args = ap.parse_args()
@@ -113,67 +222,30 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import __graft_entry__ as ge
-    ge.build()
+    if world > 1:                       # one builder per node, the others wait for the library
+        if local_rank == 0:
+            ge.build()
+        dist.barrier()
+    else:
+        ge.build()
     from list_amd import hip
     from list_amd.parallel import gather_sdf_shards
 
     inp = make_inputs(args.workload, rank, device)
     B, N = inp["B"], inp["N"]
+    _, _, img_res, vox_res, map_size, _ = WORKLOADS[args.workload]
     ev = HipEvents()
-    n_ev = hip.N_STAGES
-    # per-step events: [prep_begin, prep_img_end, prep_vox_end(=weights begin), weights_end] + stages
-    step_events = []
-    for _ in range(args.steps):
-        pre = [ev.create() for _ in range(4)]
-        arr = (ctypes.c_void_p * n_ev)(*[ev.create() for _ in range(n_ev)])
-        step_events.append((pre, arr))
-    gathered = torch.empty((world * B, N), dtype=torch.float32, device=device) if world > 1 else None
-    sdf = torch.empty((B, N), dtype=torch.float32, device=device)
-
-    def step(events=None):
-        pre, arr = events if events else (None, None)
-        if pre: ev.record(pre[0])
-        img = hip.prep_img_maps(inp["img_maps"], inp["map_size"])
-        if pre: ev.record(pre[1])
-        vox = hip.prep_vox_maps(inp["vox_maps"])
-        if pre: ev.record(pre[2])
-        packed = hip.prep_mlp_weights(inp["weights"], vox.channels, img.channels, args.precision)
-        if pre: ev.record(pre[3])
-        hip.sdf_query(inp["query"], inp["trans_mat"], img, vox, packed, precision=args.precision,
-                      out=sdf, stage_events=arr)
-        if world > 1:
-            gather_sdf_shards(sdf, out=gathered)
-        return sdf
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(step_events[i])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # ---- per-kernel-stage durations from the events recorded inside the timed region
-    names = ["prep_img_resize_nhwc", "prep_vox_ndhwc", "prep_weights"] + list(hip.STAGE_NAMES)
-    acc = np.zeros(len(names))
-    for pre, arr in step_events:
-        acc[0] += ev.elapsed_ms(pre[0], pre[1])
-        acc[1] += ev.elapsed_ms(pre[1], pre[2])
-        acc[2] += ev.elapsed_ms(pre[2], pre[3])
-        for s in range(n_ev - 1):
-            acc[3 + s] += ev.elapsed_ms(ctypes.c_void_p(arr[s]), ctypes.c_void_p(arr[s + 1]))
-    stage_ms = dict(zip(names, (acc / args.steps).tolist()))
+    headline = args.precision or "fp16"
+    elapsed, kernel_ms, sdf = run_config(args, headline, args.steps, args.warmup, inp, hip, ev, world,
+                                         device, gather_sdf_shards)
+    alt = None
+    if args.precision is None:
+        a_steps = max(2, args.steps // 2)
+        a_el, a_ms, a_sdf = run_config(args, "bf16x3", a_steps, min(args.warmup, 2), inp, hip, ev, world,
+                                       device, gather_sdf_shards)
+        alt = {"precision": "bf16x3", "value": world * B * N * a_steps / a_el, "steps": a_steps,
+               "ms_per_step": a_el / a_steps * 1e3, "kernel_ms": a_ms,
+               "max_abs_diff_vs_headline": float((a_sdf - sdf).abs().max())}
 
     if rank != 0:
         if world > 1:
@@ -183,32 +255,24 @@ def main():
     P = B * N
     value = world * P * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
-
-    # ---- roofline of the dominant kernel (stage) ------------------------------------------------
-    dom = max(hip.STAGE_NAMES, key=lambda k: stage_ms[k])
-    terms = 3 if args.precision == "bf16x3" else 1
-    vox_c = [1, 16, 32, 64, 128, 128]
-    if dom in ("gather_vox", "gather_img_tail"):
-        per_pt = (7 * 8 * sum(vox_c[1:]) * 4) if dom == "gather_vox" else (4 * 1024 * 4 + 7 * 8 * 4 + 16)
-        achieved = P * per_pt / (stage_ms[dom] * 1e-3) / 1e9
-        roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS,
-                "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": None,
-                "algorithmic_bytes_per_point": per_pt}
-    else:
-        flop_pt = {"fc_0": 2 * 3610 * 512, "fc_1": 2 * 512 * 256, "fc_2_out": 2 * (256 * 256 + 256)}[dom]
-        achieved = P * flop_pt / (stage_ms[dom] * 1e-3) / 1e12
-        roof = {"kernel": "k_gemm_nt (" + dom + ")", "bound": "mfma", "achieved": achieved,
-                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-                "traffic": None, "algorithmic_flop_per_point": flop_pt,
-                "mfma_products_per_mac": terms}
-    gather_ms = stage_ms["gather_vox"] + stage_ms["gather_img_tail"]
-    mlp_ms = stage_ms["fc_0"] + stage_ms["fc_1"] + stage_ms["fc_2_out"]
+    xb = 2 if headline != "bf16x3" else 4
+    table = kernel_table(B, N, img_res, vox_res, map_size, xb)
+    roof = roofline_of(kernel_ms, table, headline)
+    if alt is not None:
+        alt["roofline"] = roofline_of(alt["kernel_ms"], kernel_table(B, N, img_res, vox_res, map_size, 4),
+                                      "bf16x3")
+    gather_ms = sum(v for k, v in kernel_ms.items() if k.startswith("gather_"))
+    mlp_ms = kernel_ms["fc_0"] + kernel_ms["fc_1"] + kernel_ms["fc_2_out"]
     path = {
         "gather_GBps_algorithmic": P * W_BYTE_PER_PT / (gather_ms * 1e-3) / 1e9,
         "gather_frac_of_hbm_peak": P * W_BYTE_PER_PT / (gather_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
         "mlp_TFLOPs_algorithmic": P * W_FLOP_PER_PT / (mlp_ms * 1e-3) / 1e12,
         "mlp_frac_of_bf16_peak": P * W_FLOP_PER_PT / (mlp_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+        "whole_step_GBps_algorithmic": P * W_BYTE_PER_PT / (ms_per_step * 1e-3) / 1e9,
     }
+    per_kernel = {k: {"ms": kernel_ms[k], "bound": b,
+                      ("TFLOPs" if b == "mfma" else "GBps"): u / (kernel_ms[k] * 1e-3) / (1e12 if b == "mfma" else 1e9)}
+                  for k, (b, u) in table.items() if kernel_ms.get(k, 0) > 0}
 
     # ---- CPU baseline (oracle, torch-op restatement) on a bounded sample ---------------------------
     cpu = None
@@ -235,28 +299,33 @@ def main():
                              f"op sequence, fp32, no_grad), median of 3 after 1 warm-up, torch "
                              f"{torch.__version__}, os.cpu_count()={os.cpu_count()}"}
             parity = float((sdf[:ns].cpu() - ref).abs().max())
+            assert parity < 1e-4, f"parity bound violated: {parity}"
 
+    arith = {"bf16x3": "bf16 hi/lo split operands, 3 MFMA products per MAC, fp32 accumulate",
+             "fp16": "fp16 operands (saturating), 1 MFMA product per MAC, fp32 accumulate",
+             "bf16": "bf16 operands, 1 MFMA product per MAC, fp32 accumulate"}
     out = {
         "metric": "SDF query-points/sec (B=8, N=20k, 224^2)" if args.workload.endswith("n20k_224")
                   else "SDF query-points/sec",
         "value": value, "unit": "query-points/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "fp16" if args.precision == "fp16" else "bf16",
+        "scaling": "weak", "vs_baseline": None, "dtype": "fp16" if headline == "fp16" else "bf16",
         "data": "synthetic",
         "config": {"workload": args.workload, "images_per_gpu": B, "points_per_image": N,
-                   "global_points_per_step": world * P, "precision": args.precision,
-                   "mlp_arithmetic": {"bf16x3": "bf16 hi/lo split operands, 3 MFMA products per MAC, fp32 accumulate",
-                                      "fp16": "fp16 operands (saturating), 1 MFMA product per MAC, fp32 accumulate",
-                                      "bf16": "bf16 operands, 1 MFMA product per MAC, fp32 accumulate"}[args.precision],
-                   "gather_arithmetic": "fp32", "inputs": "reference layout (NCHW/NCDHW fp32) resident in HBM; "
-                   "layout hand-off + weight repack inside the timed step",
+                   "global_points_per_step": world * P, "precision": headline,
+                   "mlp_arithmetic": arith[headline], "gather_arithmetic": "fp32 (fp32 maps)",
+                   "inputs": "reference layout (NCHW/NCDHW fp32) resident in HBM; layout hand-off + weight "
+                             "repack inside the timed step",
                    "parallelism": f"batch-sharded x{world}" + (" + RCCL all-gather of sdf" if world > 1 else "")},
         "roofline": roof,
         "cpu_baseline": cpu,
-        "stage_ms": stage_ms,
+        "kernel_ms": kernel_ms,
+        "per_kernel": per_kernel,
         "path_rates": path,
         "parity_max_abs_err_vs_cpu": parity,
+        "parity_bound": 1e-4,
         "speedup_vs_cpu": (value / cpu["value"]) if cpu else None,
+        "alt": alt,
     }
     print(json.dumps(out))
     if world > 1:

@@ -145,16 +145,23 @@ typedef struct ListQueryArgs {
                                         /*   bit-identical either way), 1: keep the caller's order  */
 } ListQueryArgs;
 
-/* stage boundaries recorded into ListQueryArgs.stage_events (per row chunk; a later chunk
- * re-records, so time single-chunk calls) */
+/* Boundaries recorded into ListQueryArgs.stage_events: one hipEvent after each kernel (group) of a
+ * row chunk, so that the interval [i-1, i] is the duration of kernel i.  A later chunk re-records,
+ * so time single-chunk calls. */
 enum ListStage {
   LIST_STAGE_BEGIN = 0,   /* before the first kernel */
-  LIST_STAGE_VOX = 1,     /* after the voxel-level gathers            (modules.py:256-265) */
-  LIST_STAGE_IMG = 2,     /* after the perceptual gather + tail       (modules.py:37-52, 257) */
-  LIST_STAGE_FC0 = 3,     /* after fc_0 + ReLU                         (modules.py:276) */
-  LIST_STAGE_FC1 = 4,     /* after fc_1 + ReLU                         (modules.py:277) */
-  LIST_STAGE_FC2 = 5,     /* after fc_2 + ReLU + fc_out -> sdf         (modules.py:278-281) */
-  LIST_N_STAGES = 6
+  LIST_STAGE_SORT = 1,    /* point ordering (histogram / scan / scatter, two passes) */
+  LIST_STAGE_VOX0 = 2,    /* k_gather_vox of the 1st .. 5th vector voxel level (levels with C > 1, */
+  LIST_STAGE_VOX1 = 3,    /*   in level order; modules.py:256-265).  Unused slots are recorded     */
+  LIST_STAGE_VOX2 = 4,    /*   back to back.                                                        */
+  LIST_STAGE_VOX3 = 5,
+  LIST_STAGE_VOX4 = 6,
+  LIST_STAGE_IMG = 7,     /* k_gather_img: projection + bilinear sample  (modules.py:37-52) */
+  LIST_STAGE_TAIL = 8,    /* k_gather_tail: C == 1 level, xyz, padding   (modules.py:257) */
+  LIST_STAGE_FC0 = 9,     /* k_gemm_nt: fc_0 + ReLU                       (modules.py:276) */
+  LIST_STAGE_FC1 = 10,    /* k_gemm_nt: fc_1 + ReLU                       (modules.py:277) */
+  LIST_STAGE_FC2 = 11,    /* k_gemm_nt: fc_2 + ReLU + fc_out -> sdf       (modules.py:278-281) */
+  LIST_N_STAGES = 12
 };
 
 size_t list_query_workspace_bytes(int64_t n_points, int32_t F, int32_t H1, int32_t H2, int32_t H3);

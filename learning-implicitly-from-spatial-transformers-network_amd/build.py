@@ -32,13 +32,18 @@ def build(force=False, verbose=False):
         raise RuntimeError("hipcc not found: cannot build liblist_hip.so")
     # -ffp-contract=off: coordinates and interpolation weights must round exactly like the
     # reference's CPU ops (an fma of "scale*x - floor" skips a rounding); fmaf is explicit where wanted
-    cmd = [hipcc, "-O3", "-std=c++17", "-ffp-contract=off", f"--offload-arch={ARCH}", "-fPIC", "-shared",
-           "-I", INCLUDE, "-I", CSRC] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    cmd = [hipcc, "-O3", "-std=c++17", "-ffp-contract=off"] + os.environ.get("LIST_HIPCC_FLAGS", "").split() + [ f"--offload-arch={ARCH}", "-fPIC", "-shared",
+           "-I", INCLUDE, "-I", CSRC] + [os.path.join(CSRC, s) for s in SOURCES]
+    tmp = LIB + f".tmp{os.getpid()}"
+    cmd += ["-o", tmp]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    os.replace(tmp, LIB)            # atomic: concurrent readers never see a half-written library
     return LIB
 
 

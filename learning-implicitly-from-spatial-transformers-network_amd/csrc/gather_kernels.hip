@@ -463,6 +463,10 @@ template <int FMT>
 static hipError_t launch_gather_fmt(const GatherParams& g, const FeatLayout& L, const ListQueryArgs& a,
                                     hipStream_t s) {
   hipError_t e = hipSuccess;
+  auto mark = [&](int stage) {
+    if (a.stage_events && a.stage_events[stage]) (void)hipEventRecord((hipEvent_t)a.stage_events[stage], s);
+  };
+  int vec_level = 0;
   TailLevels tl;
   tl.n = 0;
   for (int l = 0; l < LIST_N_VOX_LEVELS; ++l) {
@@ -479,9 +483,10 @@ static hipError_t launch_gather_fmt(const GatherParams& g, const FeatLayout& L, 
       default: return hipErrorInvalidValue;
     }
     if (e != hipSuccess) return e;
+    if (vec_level < 5) mark(LIST_STAGE_VOX0 + vec_level);
+    ++vec_level;
   }
-  if (a.stage_events && a.stage_events[LIST_STAGE_VOX])
-    (void)hipEventRecord((hipEvent_t)a.stage_events[LIST_STAGE_VOX], s);
+  for (; vec_level < 5; ++vec_level) mark(LIST_STAGE_VOX0 + vec_level);
   if (a.percep_feat) {
     hipLaunchKernelGGL(k_copy_percep<FMT>, dim3((g.rows + 255) / 256), dim3(256), 0, s, g,
                        a.percep_feat, a.pf_sb, a.pf_sc, a.pf_sn, L.img_C, L.img_off);
@@ -491,6 +496,7 @@ static hipError_t launch_gather_fmt(const GatherParams& g, const FeatLayout& L, 
   }
   e = hipGetLastError();
   if (e != hipSuccess) return e;
+  mark(LIST_STAGE_IMG);
   hipLaunchKernelGGL(k_gather_tail<FMT>, dim3((g.rows + 255) / 256), dim3(256), 0, s, g, tl, L.xyz_off,
                      L.F);
   return hipGetLastError();

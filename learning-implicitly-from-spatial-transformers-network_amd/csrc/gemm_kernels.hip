@@ -35,6 +35,11 @@ template <int TERMS> struct Pipe {
   static constexpr int kWOff = (TERMS == 3 ? 2 : 1) * kPlaneBytes;
 };
 
+#ifndef LIST_GEMM_STAGE_AT
+#define LIST_GEMM_STAGE_AT 0
+#endif
+constexpr int kStageAt = LIST_GEMM_STAGE_AT;   // k16 half before which the prefetch is issued
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -117,12 +122,12 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(GemmParams p) {
     else if (younger == 1) wait_vmcnt<P::kLoadsPerStage>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    if (t + P::kAhead < nk)
-      stage_tiles<TERMS>(p, smem + ((t + P::kAhead) % P::kStages) * P::kStageBytes, m0, n0,
-                         (t + P::kAhead) * BK * 2, wave, lane);
     const char* cur = smem + (t % P::kStages) * P::kStageBytes;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
+      if (s2 == kStageAt && t + P::kAhead < nk)
+        stage_tiles<TERMS>(p, smem + ((t + P::kAhead) % P::kStages) * P::kStageBytes, m0, n0,
+                           (t + P::kAhead) * BK * 2, wave, lane);
       const int coff = ((2 * s2 + fh) ^ swz) << 4;
       bf16x8 ah[4], al[4], wh[2], wl[2];
 #pragma unroll

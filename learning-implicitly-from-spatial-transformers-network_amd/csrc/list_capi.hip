@@ -265,9 +265,10 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
         g.order_img = sb.order_img; g.row_of = sb.row_of;
       }
     }
+    mark(LIST_STAGE_SORT);
     e = launch_gather(g, L, *a, s);
     if (e != hipSuccess) return hip_fail(e, "gather launch");
-    mark(LIST_STAGE_IMG);
+    mark(LIST_STAGE_TAIL);
 
     GemmParams gp;
     memset(&gp, 0, sizeof(gp));

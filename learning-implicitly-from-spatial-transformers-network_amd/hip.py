@@ -62,8 +62,10 @@ class ListQueryArgs(C.Structure):
                 ("stage_events", C.POINTER(C.c_void_p)), ("no_sort", C.c_int32)]
 
 
-N_STAGES = 6
-STAGE_NAMES = ("gather_vox", "gather_img_tail", "fc_0", "fc_1", "fc_2_out")
+N_STAGES = 12
+# interval i = [event i, event i+1]: the kernel (group) that ends at stage i+1 of include/list_hip.h
+STAGE_NAMES = ("sort_points", "gather_vox_l1", "gather_vox_l2", "gather_vox_l3", "gather_vox_l4",
+               "gather_vox_l5", "gather_img", "gather_tail", "fc_0", "fc_1", "fc_2_out")
 
 
 class ListPoolArgs(C.Structure):
