@@ -155,7 +155,8 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     names = ["prep_img_resize_nhwc", "prep_vox_ndhwc", "prep_weights"] + list(hip.STAGE_NAMES)
@@ -215,11 +216,18 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
         args.gpus = world
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # LIST_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the control flow of the
+    # N > 1 path on a single-GPU box (RCCL refuses duplicate devices); the driver uses nccl (= RCCL).
+    backend = os.environ.get("LIST_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import __graft_entry__ as ge
     if world > 1:                       # one builder per node, the others wait for the library

@@ -142,6 +142,149 @@ __global__ __launch_bounds__(256) void k_gather_vox(GatherParams g, ListVoxLevel
   }
 }
 
+// ---- coarse levels: the 7 stencil points share their taps ---------------------------------------------
+// When the displacement is shorter than one voxel (d * (size-1)/2 < 1: the 16^3 and 8^3 levels) the
+// -d / +d stencil points sample either the centre's cell or the adjacent one, so all 7 samples are
+// weighted sums over a "plus" of voxels: 4 x-planes x (2x2 in y,z) + 2 extra y-planes + 2 extra
+// z-planes = 32 distinct taps instead of 7 x 8 = 56 (these two levels carry 58 % of all tap bytes and
+// are L1-bandwidth bound).  Each axis is factored: P[k] = sum over the centre's 2x2 of the other two
+// axes of plane k, then out_j = sum_k w_j[k] P[k] with the 4-entry weight vector of stencil point j
+// (two non-zeros).  Same taps and weights as the reference; only the summation order differs.
+struct Win { int i[4]; };     // the 4 plane indices c-1, c, c+1, c+2 clamped to [0, size-1]
+
+__device__ __forceinline__ void window_weights(const Axis& a, int cbase, float (&w)[4]) {
+  // Axis a samples planes a.i0 and a.i0+1 (if has1); cbase = index of window slot 0
+  const int k0 = a.i0 - cbase;            // 0, 1 or 2
+#pragma unroll
+  for (int k = 0; k < 4; ++k) w[k] = (k == k0) ? a.w0 : ((k == k0 + 1 && a.has1) ? a.w1 : 0.f);
+}
+
+__device__ __forceinline__ float4 wsum4(const float4 (&P)[4], const float (&w)[4]) {
+  float4 r = make_float4(P[0].x * w[0], P[0].y * w[0], P[0].z * w[0], P[0].w * w[0]);
+  r = fma4(P[1], w[1], r); r = fma4(P[2], w[2], r); r = fma4(P[3], w[3], r);
+  return r;
+}
+
+template <int C, int FMT>
+__global__ __launch_bounds__(256) void k_gather_vox_near(GatherParams g, ListVoxLevel lv, int col_off) {
+  constexpr int LP = C / 4;
+  constexpr int PW = 64 / LP;
+  constexpr int ITERS = (4 * PW >= kGatherRows) ? 1 : kGatherRows / (4 * PW);
+  constexpr int RB = 4 * PW * ITERS;
+  __shared__ Pt pts[RB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int quad = lane % LP, psub = lane / LP;
+  const int blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  if (threadIdx.x < RB) pts[threadIdx.x] = load_point(g, blk * RB + threadIdx.x);
+  __syncthreads();
+  unsigned short* __restrict__ xh = g.x_hi;
+  unsigned short* __restrict__ xl = g.x_lo;
+  const int W = lv.W, H = lv.H, D = lv.D;
+#pragma unroll 1
+  for (int it = 0; it < ITERS; ++it) {
+    const int local = it * (4 * PW) + wave * PW + psub;
+    const int row = blk * RB + local;
+    const Pt p = pts[local];
+    const float* __restrict__ base = lv.data + (int64_t)p.b * lv.image_stride + quad * 4;
+    const int64_t out_off = (int64_t)row * g.Kp + col_off + quad * 4;
+
+    const Axis cx = axis_setup(p.x, W), cy = axis_setup(p.y, H), cz = axis_setup(p.z, D);
+    const Axis mx = axis_setup(p.x - kDisp, W), px = axis_setup(p.x + kDisp, W);
+    const Axis my = axis_setup(p.y - kDisp, H), py = axis_setup(p.y + kDisp, H);
+    const Axis mz = axis_setup(p.z - kDisp, D), pz = axis_setup(p.z + kDisp, D);
+    // element offsets of the window planes (clamped; clamped-away slots always get weight 0)
+    int ox[4], oy[4], oz[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ox[k] = min(max(cx.i0 - 1 + k, 0), W - 1) * C;
+      oy[k] = min(max(cy.i0 - 1 + k, 0), H - 1) * W * C;
+      oz[k] = min(max(cz.i0 - 1 + k, 0), D - 1) * H * W * C;
+    }
+    float wcx[4], wcy[4], wcz[4], wmx[4], wpx[4], wmy[4], wpy[4], wmz[4], wpz[4];
+    window_weights(cx, cx.i0 - 1, wcx); window_weights(cy, cy.i0 - 1, wcy); window_weights(cz, cz.i0 - 1, wcz);
+    window_weights(mx, cx.i0 - 1, wmx); window_weights(px, cx.i0 - 1, wpx);
+    window_weights(my, cy.i0 - 1, wmy); window_weights(py, cy.i0 - 1, wpy);
+    window_weights(mz, cz.i0 - 1, wmz); window_weights(pz, cz.i0 - 1, wpz);
+    // centre 2x2 weights of each axis pair (window slots 1 and 2)
+    const float wyz[4] = {wcy[1] * wcz[1], wcy[2] * wcz[1], wcy[1] * wcz[2], wcy[2] * wcz[2]};
+    const float wxz[4] = {wcx[1] * wcz[1], wcx[2] * wcz[1], wcx[1] * wcz[2], wcx[2] * wcz[2]};
+    const float wxy[4] = {wcx[1] * wcy[1], wcx[2] * wcy[1], wcx[1] * wcy[2], wcx[2] * wcy[2]};
+
+    // phase 1: 4 x-planes x centre (y,z) 2x2 -> stencil points 0, 1, 2
+    float4 A[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      A[k][0] = *(const float4*)(base + oz[1] + oy[1] + ox[k]);
+      A[k][1] = *(const float4*)(base + oz[1] + oy[2] + ox[k]);
+      A[k][2] = *(const float4*)(base + oz[2] + oy[1] + ox[k]);
+      A[k][3] = *(const float4*)(base + oz[2] + oy[2] + ox[k]);
+    }
+    // phase 2/3 loads: the two extra y-planes and z-planes over the centre 2x2 of the other axes
+    float4 By[2][4], Bz[2][4];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int ky = e ? 3 : 0, kz = e ? 3 : 0;
+      By[e][0] = *(const float4*)(base + oz[1] + oy[ky] + ox[1]);
+      By[e][1] = *(const float4*)(base + oz[1] + oy[ky] + ox[2]);
+      By[e][2] = *(const float4*)(base + oz[2] + oy[ky] + ox[1]);
+      By[e][3] = *(const float4*)(base + oz[2] + oy[ky] + ox[2]);
+      Bz[e][0] = *(const float4*)(base + oz[kz] + oy[1] + ox[1]);
+      Bz[e][1] = *(const float4*)(base + oz[kz] + oy[1] + ox[2]);
+      Bz[e][2] = *(const float4*)(base + oz[kz] + oy[2] + ox[1]);
+      Bz[e][3] = *(const float4*)(base + oz[kz] + oy[2] + ox[2]);
+    }
+    float4 P[4];
+    float4 out[7];
+    // x axis
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float4 r = make_float4(A[k][0].x * wyz[0], A[k][0].y * wyz[0], A[k][0].z * wyz[0], A[k][0].w * wyz[0]);
+      r = fma4(A[k][1], wyz[1], r); r = fma4(A[k][2], wyz[2], r); r = fma4(A[k][3], wyz[3], r);
+      P[k] = r;
+    }
+    out[0] = wsum4(P, wcx); out[1] = wsum4(P, wmx); out[2] = wsum4(P, wpx);
+    // y axis: planes 1,2 come from A (x = slots 1,2), planes 0,3 from By
+    {
+      float4 r;
+      r = make_float4(By[0][0].x * wxz[0], By[0][0].y * wxz[0], By[0][0].z * wxz[0], By[0][0].w * wxz[0]);
+      r = fma4(By[0][1], wxz[1], r); r = fma4(By[0][2], wxz[2], r); r = fma4(By[0][3], wxz[3], r);
+      P[0] = r;
+      r = make_float4(A[1][0].x * wxz[0], A[1][0].y * wxz[0], A[1][0].z * wxz[0], A[1][0].w * wxz[0]);
+      r = fma4(A[2][0], wxz[1], r); r = fma4(A[1][2], wxz[2], r); r = fma4(A[2][2], wxz[3], r);
+      P[1] = r;
+      r = make_float4(A[1][1].x * wxz[0], A[1][1].y * wxz[0], A[1][1].z * wxz[0], A[1][1].w * wxz[0]);
+      r = fma4(A[2][1], wxz[1], r); r = fma4(A[1][3], wxz[2], r); r = fma4(A[2][3], wxz[3], r);
+      P[2] = r;
+      r = make_float4(By[1][0].x * wxz[0], By[1][0].y * wxz[0], By[1][0].z * wxz[0], By[1][0].w * wxz[0]);
+      r = fma4(By[1][1], wxz[1], r); r = fma4(By[1][2], wxz[2], r); r = fma4(By[1][3], wxz[3], r);
+      P[3] = r;
+    }
+    out[3] = wsum4(P, wmy); out[4] = wsum4(P, wpy);
+    // z axis: planes 1,2 from A, planes 0,3 from Bz
+    {
+      float4 r;
+      r = make_float4(Bz[0][0].x * wxy[0], Bz[0][0].y * wxy[0], Bz[0][0].z * wxy[0], Bz[0][0].w * wxy[0]);
+      r = fma4(Bz[0][1], wxy[1], r); r = fma4(Bz[0][2], wxy[2], r); r = fma4(Bz[0][3], wxy[3], r);
+      P[0] = r;
+      r = make_float4(A[1][0].x * wxy[0], A[1][0].y * wxy[0], A[1][0].z * wxy[0], A[1][0].w * wxy[0]);
+      r = fma4(A[2][0], wxy[1], r); r = fma4(A[1][1], wxy[2], r); r = fma4(A[2][1], wxy[3], r);
+      P[1] = r;
+      r = make_float4(A[1][2].x * wxy[0], A[1][2].y * wxy[0], A[1][2].z * wxy[0], A[1][2].w * wxy[0]);
+      r = fma4(A[2][2], wxy[1], r); r = fma4(A[1][3], wxy[2], r); r = fma4(A[2][3], wxy[3], r);
+      P[2] = r;
+      r = make_float4(Bz[1][0].x * wxy[0], Bz[1][0].y * wxy[0], Bz[1][0].z * wxy[0], Bz[1][0].w * wxy[0]);
+      r = fma4(Bz[1][1], wxy[1], r); r = fma4(Bz[1][2], wxy[2], r); r = fma4(Bz[1][3], wxy[3], r);
+      P[3] = r;
+    }
+    out[5] = wsum4(P, wmz); out[6] = wsum4(P, wpz);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      if (!p.valid) out[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      store_feat4<FMT>(xh, xl, out_off + j * C, out[j]);
+    }
+  }
+}
+
 // ---- 2-D perceptual pooling ---------------------------------------------------------------------
 // network/modules.py:37-47 per point.  torch.matmul evaluates the K=4 dot product as an fma chain
 // in k order (oracle/list_oracle.py project_points, checked bit-for-bit).
@@ -455,7 +598,12 @@ static hipError_t launch_vox_level(const GatherParams& g, const ListVoxLevel& lv
                                    hipStream_t s) {
   constexpr int PW = 64 / (C / 4);
   constexpr int RB = (4 * PW >= kGatherRows) ? 4 * PW : kGatherRows;
-  hipLaunchKernelGGL((k_gather_vox<C, FMT>), dim3(g.rows / RB), dim3(256), 0, s, g, lv, col_off);
+  const int big = lv.W > lv.H ? (lv.W > lv.D ? lv.W : lv.D) : (lv.H > lv.D ? lv.H : lv.D);
+  const bool near = kDisp * 0.5f * (float)(big - 1) < 0.99f && C >= 16;   // stencil stays within one cell
+  if (near)
+    hipLaunchKernelGGL((k_gather_vox_near<C, FMT>), dim3(g.rows / RB), dim3(256), 0, s, g, lv, col_off);
+  else
+    hipLaunchKernelGGL((k_gather_vox<C, FMT>), dim3(g.rows / RB), dim3(256), 0, s, g, lv, col_off);
   return hipGetLastError();
 }
 

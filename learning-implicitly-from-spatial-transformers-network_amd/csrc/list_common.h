@@ -12,6 +12,7 @@ namespace list {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int kRowTile = 256;       // GEMM BM: workspace rows are padded to this
 constexpr int kKTile = 32;          // GEMM BK: feature columns are padded to this
@@ -52,13 +53,17 @@ enum { FMT_BF16_SPLIT = 0, FMT_FP16 = 1 };     // element format of X / H / pack
 template <int FMT>
 __device__ __forceinline__ void store_feat4(unsigned short* x_hi, unsigned short* x_lo, int64_t off,
                                             const float4& v) {
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+  // X is written once and next read by the MLP kernel: non-temporal stores keep it from evicting
+  // the map lines the gathers are re-reading from L2 (measured: 2-D gather 0.30 -> 0.25 ms)
   if (FMT == FMT_FP16) {
-    *(uint2*)(x_hi + off) = half4(v);
+    const uint2 h = half4(v);
+    __builtin_nontemporal_store((u32x2){h.x, h.y}, (u32x2*)(x_hi + off));
   } else {
     uint2 hi, lo;
     split4(v, hi, lo);
-    *(uint2*)(x_hi + off) = hi;
-    *(uint2*)(x_lo + off) = lo;
+    __builtin_nontemporal_store((u32x2){hi.x, hi.y}, (u32x2*)(x_hi + off));
+    __builtin_nontemporal_store((u32x2){lo.x, lo.y}, (u32x2*)(x_lo + off));
   }
 }
 template <int FMT>

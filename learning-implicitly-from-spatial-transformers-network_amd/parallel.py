@@ -40,6 +40,12 @@ def gather_sdf_shards(sdf_local, out=None, group=None):
     if out is None:
         out = torch.empty((world * sdf_local.shape[0],) + tuple(sdf_local.shape[1:]),
                           dtype=sdf_local.dtype, device=sdf_local.device)
+    if sdf_local.is_cuda and dist.get_backend(group) != "nccl":
+        # CPU-side backends (gloo rehearsals): stage through the host
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, sdf_local.cpu(), group=group)
+        out.copy_(host)
+        return out
     dist.all_gather_into_tensor(out, sdf_local, group=group)
     return out
 
