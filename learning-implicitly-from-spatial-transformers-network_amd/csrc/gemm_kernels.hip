@@ -5,40 +5,49 @@
 //                     fp32 accumulate; the dropped lo.lo term is ~2^-16 relative)
 //   precision BF16  : acc += A_hi.W_hi
 //
-// Tiling (CDNA4, wave64): workgroup 256x256 outputs, BK = 32, 8 waves as 2(M) x 4(N), each wave
-// 128x64 = 4x2 tiles of 32x32 (128 accumulator registers).  Operand tiles go HBM/L2 -> LDS with
-// global_load_lds_dwordx4 (no VGPR round trip), double-buffered: 4 planes x 16 KB x 2 stages =
-// 128 KB LDS, one workgroup per CU.  LDS rows are 64 B (32 bf16); the 16-B chunk index is XORed
-// with (row>>2)&3 -- on the SOURCE address for the linear LDS-DMA write and on the ds_read_b128
-// address -- so the 16 lanes of every ds_read_b128 lane group hit 16 distinct bank quads.
+// Tiling (CDNA4, wave64): workgroup 256x256 outputs, 8 waves as 2(M) x 4(N), each wave 128x64 =
+// 4x2 tiles of 32x32 (128 accumulator registers).  Operand tiles go HBM/L2 -> LDS with
+// global_load_lds_dwordx4 (no VGPR round trip), double-buffered 64-KB stages (128 KB LDS, one
+// workgroup per CU).  LDS rows are 64 B (BK = 32) or 128 B (BK = 64); the 16-B chunk index is XORed
+// with (row>>2)&3 resp. (row>>1)&7 -- on the SOURCE address for the linear LDS-DMA write and on the
+// ds_read_b128 address -- so the 16 lanes of every ds_read_b128 lane group hit 16 distinct 16-B
+// slots of the 256-B bank row.
 // Epilogues: bias+ReLU+bf16 split store (hidden layers), fp32 store (tests), and
 // bias+ReLU+dot(w3)+b3 -> sdf (fc_2 and fc_out fused; needs N == 256).
 #include "list_common.h"
 
 namespace list {
 
-constexpr int BM = 256, BN = 256, BK = 32;
-constexpr int kPlaneBytes = BM * BK * 2;        // 16 KB: one operand plane of one stage
-constexpr int kLdsBytes = 8 * kPlaneBytes;      // 128 KB = 2 stages x 4 planes or 4 stages x 2 planes
+constexpr int BM = 256, BN = 256;
+constexpr int kLdsBytes = 131072;               // 128 KB of the CU's 160 KB
 
-// Software pipeline.  A stage = the operand planes of one K-step: {A_hi, A_lo, W_hi, W_lo} (TERMS = 3,
-// 64 KB, 2 stages) or {A, W} (TERMS = 1, 32 KB, 4 stages).  LDS-DMA loads run D = NST-1 K-steps
-// ahead; the only waits in the loop are a COUNTED s_waitcnt vmcnt (the wave's own pieces of the
-// oldest stage have landed, the younger stages stay in flight) followed by ONE raw s_barrier (every
-// wave's pieces have landed, and every wave is done reading the buffer about to be refilled).
+// Software pipeline.  A stage = the operand planes of one K-step:
+//   TERMS = 3 (bf16 hi/lo): {A_hi, A_lo, W_hi, W_lo}, BK = 32 (64-B rows),  4 x 16 KB, 2 stages;
+//   TERMS = 1 (fp16/bf16) : {A, W},                   BK = 64 (128-B rows), 2 x 32 KB, 2 stages.
+// With one plane per operand the K-step is 64 so that every LDS-DMA row segment is a full 128-B
+// line: 64-B half-line requests cap the L2 -> LDS rate near 30 GB/s per CU (measured: the load path
+// alone took 0.60 ms of fc_0's 0.64 ms), full lines roughly double it.
+// LDS-DMA loads run kAhead K-steps ahead; the only waits in the loop are a COUNTED s_waitcnt vmcnt
+// (the wave's own pieces of the oldest stage have landed, younger stages stay in flight) followed by
+// ONE raw s_barrier (every wave's pieces have landed, and every wave is done reading the buffer
+// about to be refilled).
 template <int TERMS> struct Pipe {
   static constexpr int kPlanes = TERMS == 3 ? 4 : 2;
-  static constexpr int kStageBytes = kPlanes * kPlaneBytes;
-  static constexpr int kStages = kLdsBytes / kStageBytes;       // 2 or 4
-  static constexpr int kAhead = kStages - 1;                    // 1 or 3
-  static constexpr int kLoadsPerStage = 2 * kPlanes;            // glds issued per wave per stage
+  static constexpr int BK = TERMS == 3 ? 32 : 64;
+  static constexpr int kRowBytes = BK * 2;                      // 64 or 128
+  static constexpr int kPlaneBytes = BM * kRowBytes;            // 16 or 32 KB
+  static constexpr int kStageBytes = kPlanes * kPlaneBytes;     // 64 KB
+  static constexpr int kStages = kLdsBytes / kStageBytes;       // 2
+  static constexpr int kAhead = kStages - 1;                    // 1
+  static constexpr int kRowsPerPiece = 1024 / kRowBytes;        // rows moved by one 1-KB LDS-DMA
+  static constexpr int kPiecesPerWave = BM / kRowsPerPiece / 8; // per plane per wave: 2 or 4
+  static constexpr int kLoadsPerStage = kPiecesPerWave * kPlanes;
   static constexpr int kWOff = (TERMS == 3 ? 2 : 1) * kPlaneBytes;
+  // XOR swizzle of the 16-B chunk index inside a row (conflict-free ds_read_b128, see header)
+  __device__ static __forceinline__ int swz(int row) {
+    return kRowBytes == 64 ? ((row >> 2) & 3) : ((row >> 1) & 7);
+  }
 };
-
-#ifndef LIST_GEMM_STAGE_AT
-#define LIST_GEMM_STAGE_AT 0
-#endif
-constexpr int kStageAt = LIST_GEMM_STAGE_AT;   // k16 half before which the prefetch is issued
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -50,25 +59,28 @@ __device__ __forceinline__ void glds16(const char* g, char* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-// Each wave stages two 16-row blocks (1 KB each) of every plane.  Lane i of a piece writes LDS
-// bytes [16 i, 16 i + 16) of the block = (row i>>2, physical chunk i&3); it must fetch the
-// LOGICAL chunk (i&3) ^ ((row>>2)&3) of that row.
+// Each wave stages kPiecesPerWave 1-KB pieces of every plane.  Lane i of a piece writes LDS bytes
+// [16 i, 16 i + 16) of the piece = (row i / chunks_per_row, physical chunk i % chunks_per_row); it
+// must fetch the LOGICAL chunk phys ^ swz(row) of that row (the LDS image stays lane-linear, the
+// swizzle lives in the per-lane SOURCE address and in the ds_read address).
 template <int TERMS>
 __device__ __forceinline__ void stage_tiles(const GemmParams& p, char* sbase, int m0, int n0,
                                             int kbyte, int wave, int lane) {
-  const int chunk = (lane & 3) ^ ((lane >> 4) & 3);
+  using P = Pipe<TERMS>;
+  constexpr int CPR = P::kRowBytes / 16;                 // chunks per row: 4 or 8
   const int64_t ld = (int64_t)p.K * 2;
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int rb = 2 * wave + r;
-    const int row = rb * 16 + (lane >> 2);
+  for (int r = 0; r < P::kPiecesPerWave; ++r) {
+    const int piece = P::kPiecesPerWave * wave + r;
+    const int row = piece * P::kRowsPerPiece + lane / CPR;
+    const int chunk = (lane % CPR) ^ P::swz(row);
     const int64_t aoff = (int64_t)(m0 + row) * ld + kbyte + chunk * 16;
     const int64_t woff = (int64_t)(n0 + row) * ld + kbyte + chunk * 16;
-    char* l = sbase + rb * 1024;
+    char* l = sbase + piece * 1024;
     glds16(p.a_hi + aoff, l);
-    if (TERMS == 3) glds16(p.a_lo + aoff, l + kPlaneBytes);
-    glds16(p.w_hi + woff, l + Pipe<TERMS>::kWOff);
-    if (TERMS == 3) glds16(p.w_lo + woff, l + Pipe<TERMS>::kWOff + kPlaneBytes);
+    if (TERMS == 3) glds16(p.a_lo + aoff, l + P::kPlaneBytes);
+    glds16(p.w_hi + woff, l + P::kWOff);
+    if (TERMS == 3) glds16(p.w_lo + woff, l + P::kWOff + P::kPlaneBytes);
   }
 }
 
@@ -106,15 +118,16 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(GemmParams p) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   // fragment addresses: lane l holds A[row l&31][k = 8*(l>>5) .. +7] of each 32x16 operand block
-  const int frow = lane & 31, fh = lane >> 5, swz = (lane >> 2) & 3;
-  const int a_row_off = (wm * 128 + frow) * 64;
-  const int w_row_off = (wn * 64 + frow) * 64;
-
   using P = Pipe<TERMS>;
-  const int nk = p.K / BK;
+  const int frow = lane & 31, fh = lane >> 5;
+  const int fswz = P::swz(frow);                       // tile row offsets are multiples of 32
+  const int a_row_off = (wm * 128 + frow) * P::kRowBytes;
+  const int w_row_off = (wn * 64 + frow) * P::kRowBytes;
+
+  const int nk = p.K / P::BK;
 #pragma unroll
   for (int s = 0; s < P::kAhead; ++s)
-    if (s < nk) stage_tiles<TERMS>(p, smem + s * P::kStageBytes, m0, n0, s * BK * 2, wave, lane);
+    if (s < nk) stage_tiles<TERMS>(p, smem + s * P::kStageBytes, m0, n0, s * P::kRowBytes, wave, lane);
   for (int t = 0; t < nk; ++t) {
     // stage t must have landed; stages t+1 .. t+kAhead-1 (those that exist) may stay in flight
     const int younger = min(P::kAhead - 1, nk - 1 - t);
@@ -122,23 +135,27 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(GemmParams p) {
     else if (younger == 1) wait_vmcnt<P::kLoadsPerStage>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+#ifndef LIST_GEMM_NO_LOAD
+    if (t + P::kAhead < nk)
+      stage_tiles<TERMS>(p, smem + ((t + P::kAhead) % P::kStages) * P::kStageBytes, m0, n0,
+                         (t + P::kAhead) * P::kRowBytes, wave, lane);
+#endif
     const char* cur = smem + (t % P::kStages) * P::kStageBytes;
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      if (s2 == kStageAt && t + P::kAhead < nk)
-        stage_tiles<TERMS>(p, smem + ((t + P::kAhead) % P::kStages) * P::kStageBytes, m0, n0,
-                           (t + P::kAhead) * BK * 2, wave, lane);
-      const int coff = ((2 * s2 + fh) ^ swz) << 4;
+    for (int s2 = 0; s2 < P::BK / 16; ++s2) {
+      const int coff = ((2 * s2 + fh) ^ fswz) << 4;
       bf16x8 ah[4], al[4], wh[2], wl[2];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        ah[i] = *(const bf16x8*)(cur + a_row_off + i * 32 * 64 + coff);
-        if (TERMS == 3) al[i] = *(const bf16x8*)(cur + kPlaneBytes + a_row_off + i * 32 * 64 + coff);
+        ah[i] = *(const bf16x8*)(cur + a_row_off + i * 32 * P::kRowBytes + coff);
+        if (TERMS == 3)
+          al[i] = *(const bf16x8*)(cur + P::kPlaneBytes + a_row_off + i * 32 * P::kRowBytes + coff);
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        wh[j] = *(const bf16x8*)(cur + P::kWOff + w_row_off + j * 32 * 64 + coff);
-        if (TERMS == 3) wl[j] = *(const bf16x8*)(cur + P::kWOff + kPlaneBytes + w_row_off + j * 32 * 64 + coff);
+        wh[j] = *(const bf16x8*)(cur + P::kWOff + w_row_off + j * 32 * P::kRowBytes + coff);
+        if (TERMS == 3)
+          wl[j] = *(const bf16x8*)(cur + P::kWOff + P::kPlaneBytes + w_row_off + j * 32 * P::kRowBytes + coff);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -148,7 +165,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(GemmParams p) {
             acc[i][j] = mfma<0>(al[i], wh[j], acc[i][j]);
             acc[i][j] = mfma<0>(ah[i], wl[j], acc[i][j]);
           }
+#ifdef LIST_GEMM_NO_MFMA
+          asm volatile("" ::"v"(ah[i]), "v"(wh[j]));
+#else
           acc[i][j] = mfma<FP16>(ah[i], wh[j], acc[i][j]);
+#endif
         }
     }
   }
@@ -249,7 +270,7 @@ static hipError_t launch_epi(const GemmParams& p, int epi, hipStream_t s) {
 }
 
 hipError_t launch_gemm(const GemmParams& p, int terms, int epi, hipStream_t s) {
-  if (p.M % BM || p.N % BN || p.K % BK || p.M <= 0) return hipErrorInvalidValue;
+  if (p.M % BM || p.N % BN || p.K % 64 || p.M <= 0) return hipErrorInvalidValue;
   if (epi == EPI_RELU_DOT && p.N != BN) return hipErrorInvalidValue;
   if (p.fmt == FMT_FP16) return launch_epi<1, 1>(p, epi, s);
   if (terms == 3) return launch_epi<3, 0>(p, epi, s);

@@ -353,8 +353,8 @@ int list_gemm_nt(const void* a_hi, const void* a_lo, const void* w_hi, const voi
   if (!a_hi || !w_hi || !out) return fail(LIST_ERR_ARG, "NULL pointer");
   if (precision == LIST_PREC_BF16X3 && (!a_lo || !w_lo)) return fail(LIST_ERR_ARG, "lo planes missing");
   if (precision < LIST_PREC_BF16X3 || precision > LIST_PREC_FP16) return fail(LIST_ERR_ARG, "precision=%d", precision);
-  if (M <= 0 || M % 256 || N <= 0 || N % 256 || K <= 0 || K % 32)
-    return fail(LIST_ERR_SHAPE, "M=%d N=%d K=%d (need M,N %% 256 == 0, K %% 32 == 0)", M, N, K);
+  if (M <= 0 || M % 256 || N <= 0 || N % 256 || K <= 0 || K % 64)
+    return fail(LIST_ERR_SHAPE, "M=%d N=%d K=%d (need M,N %% 256 == 0, K %% 64 == 0)", M, N, K);
   if (!aligned16(a_hi) || !aligned16(w_hi) || (a_lo && !aligned16(a_lo)) || (w_lo && !aligned16(w_lo)))
     return fail(LIST_ERR_SHAPE, "operands must be 16-byte aligned");
   GemmParams gp;

@@ -15,7 +15,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int kRowTile = 256;       // GEMM BM: workspace rows are padded to this
-constexpr int kKTile = 32;          // GEMM BK: feature columns are padded to this
+constexpr int kKTile = 64;          // GEMM BK (largest): feature columns are padded to this
 constexpr int kGatherRows = 64;     // query points per gather workgroup
 constexpr float kDisp = 0.0722f;    // stencil displacement, network/modules.py:205
 

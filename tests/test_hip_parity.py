@@ -62,7 +62,7 @@ def test_split_bf16_is_rne_hi_plus_lo(hip):
     assert np.abs(rec - x).max() <= np.abs(x).max() * 2.0 ** -16
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 32), (512, 256, 256), (256, 512, 3648), (768, 512, 512)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 256, 256), (256, 512, 3648), (768, 512, 512)])
 def test_gemm_kernel_matches_fp64(hip, M, N, K):
     a = synth.normalish(1, (M, K))
     w = synth.uniform(2, (N, K), -0.05, 0.05)
