@@ -499,24 +499,30 @@ __global__ __launch_bounds__(256) void k_gather_img(GatherParams g, const float*
   unsigned short* __restrict__ xh = g.x_hi;
   unsigned short* __restrict__ xl = g.x_lo;
   const int64_t img_stride = (int64_t)ms * ms * Ct;
+#ifndef LIST_IMG_PTS
+#define LIST_IMG_PTS 2
+#endif
+  constexpr int NP = LIST_IMG_PTS;      // points in flight per step: 4 * NP 16-B loads per lane
 #pragma unroll 1
-  for (int i = 0; i < kGatherRows; i += 2) {
-    const ImgPoint a = ipt[i], c = ipt[i + 1];
-    const float* __restrict__ ia = img_map + a.b * img_stride;
-    const float* __restrict__ ic = img_map + c.b * img_stride;
+  for (int i = 0; i < kGatherRows; i += NP) {
     for (int q = threadIdx.x; q < nq; q += 256) {
-      const float4 a00 = *(const float4*)(ia + a.pr.o00 + q * 4), a01 = *(const float4*)(ia + a.pr.o01 + q * 4);
-      const float4 a10 = *(const float4*)(ia + a.pr.o10 + q * 4), a11 = *(const float4*)(ia + a.pr.o11 + q * 4);
-      const float4 c00 = *(const float4*)(ic + c.pr.o00 + q * 4), c01 = *(const float4*)(ic + c.pr.o01 + q * 4);
-      const float4 c10 = *(const float4*)(ic + c.pr.o10 + q * 4), c11 = *(const float4*)(ic + c.pr.o11 + q * 4);
-      float4 ra = make_float4(a00.x * a.pr.w00, a00.y * a.pr.w00, a00.z * a.pr.w00, a00.w * a.pr.w00);
-      ra = fma4(a01, a.pr.w01, ra); ra = fma4(a10, a.pr.w10, ra); ra = fma4(a11, a.pr.w11, ra);
-      float4 rc = make_float4(c00.x * c.pr.w00, c00.y * c.pr.w00, c00.z * c.pr.w00, c00.w * c.pr.w00);
-      rc = fma4(c01, c.pr.w01, rc); rc = fma4(c10, c.pr.w10, rc); rc = fma4(c11, c.pr.w11, rc);
-      if (!a.valid) ra = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!c.valid) rc = make_float4(0.f, 0.f, 0.f, 0.f);
-      store_feat4<FMT>(xh, xl, (int64_t)a.row * g.Kp + col_off + q * 4, ra);
-      store_feat4<FMT>(xh, xl, (int64_t)c.row * g.Kp + col_off + q * 4, rc);
+      float4 v[NP][4];
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const ImgPoint& a = ipt[i + k];
+        const float* __restrict__ ia = img_map + a.b * img_stride + q * 4;
+        v[k][0] = *(const float4*)(ia + a.pr.o00); v[k][1] = *(const float4*)(ia + a.pr.o01);
+        v[k][2] = *(const float4*)(ia + a.pr.o10); v[k][3] = *(const float4*)(ia + a.pr.o11);
+      }
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const ImgPoint& a = ipt[i + k];
+        float4 r = make_float4(v[k][0].x * a.pr.w00, v[k][0].y * a.pr.w00, v[k][0].z * a.pr.w00,
+                               v[k][0].w * a.pr.w00);
+        r = fma4(v[k][1], a.pr.w01, r); r = fma4(v[k][2], a.pr.w10, r); r = fma4(v[k][3], a.pr.w11, r);
+        if (!a.valid) r = make_float4(0.f, 0.f, 0.f, 0.f);
+        store_feat4<FMT>(xh, xl, (int64_t)a.row * g.Kp + col_off + q * 4, r);
+      }
     }
   }
 }

@@ -141,34 +141,43 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(GemmParams p) {
                          (t + P::kAhead) * P::kRowBytes, wave, lane);
 #endif
     const char* cur = smem + (t % P::kStages) * P::kStageBytes;
-#pragma unroll
-    for (int s2 = 0; s2 < P::BK / 16; ++s2) {
+    // Register double-buffered fragments: the ds_reads of k16-step s2+1 are issued ahead of the MFMAs
+    // of step s2 (written as one buffer, hipcc reuses four fragment registers and exposes an
+    // lgkmcnt(0) round trip every four MFMAs; sched_group_barrier pinning measured no further gain).
+    constexpr int NS = P::BK / 16;
+    bf16x8 ah[2][4], al[2][4], wh[2][2], wl[2][2];
+    auto load_frags = [&](int s2, int buf) {
       const int coff = ((2 * s2 + fh) ^ fswz) << 4;
-      bf16x8 ah[4], al[4], wh[2], wl[2];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        ah[i] = *(const bf16x8*)(cur + a_row_off + i * 32 * P::kRowBytes + coff);
+        ah[buf][i] = *(const bf16x8*)(cur + a_row_off + i * 32 * P::kRowBytes + coff);
         if (TERMS == 3)
-          al[i] = *(const bf16x8*)(cur + P::kPlaneBytes + a_row_off + i * 32 * P::kRowBytes + coff);
+          al[buf][i] = *(const bf16x8*)(cur + P::kPlaneBytes + a_row_off + i * 32 * P::kRowBytes + coff);
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        wh[j] = *(const bf16x8*)(cur + P::kWOff + w_row_off + j * 32 * P::kRowBytes + coff);
+        wh[buf][j] = *(const bf16x8*)(cur + P::kWOff + w_row_off + j * 32 * P::kRowBytes + coff);
         if (TERMS == 3)
-          wl[j] = *(const bf16x8*)(cur + P::kWOff + P::kPlaneBytes + w_row_off + j * 32 * P::kRowBytes + coff);
+          wl[buf][j] = *(const bf16x8*)(cur + P::kWOff + P::kPlaneBytes + w_row_off + j * 32 * P::kRowBytes + coff);
       }
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) {
+      const int b = s2 & 1;
+      if (s2 + 1 < NS) load_frags(s2 + 1, b ^ 1);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           if (TERMS == 3) {
-            acc[i][j] = mfma<0>(al[i], wh[j], acc[i][j]);
-            acc[i][j] = mfma<0>(ah[i], wl[j], acc[i][j]);
+            acc[i][j] = mfma<0>(al[b][i], wh[b][j], acc[i][j]);
+            acc[i][j] = mfma<0>(ah[b][i], wl[b][j], acc[i][j]);
           }
 #ifdef LIST_GEMM_NO_MFMA
-          asm volatile("" ::"v"(ah[i]), "v"(wh[j]));
+          asm volatile("" ::"v"(ah[b][i]), "v"(wh[b][j]));
 #else
-          acc[i][j] = mfma<FP16>(ah[i], wh[j], acc[i][j]);
+          acc[i][j] = mfma<FP16>(ah[b][i], wh[b][j], acc[i][j]);
 #endif
         }
     }
