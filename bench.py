@@ -92,8 +92,10 @@ def make_inputs(workload, rank, device):
 VOX_C = [1, 16, 32, 64, 128, 128]
 
 
-def kernel_table(B, N, img_res, vox_res, map_size, x_bytes_per_feature):
-    """name -> (bound, algorithmic units per step)."""
+def kernel_table(B, N, img_res, vox_res, map_size, x_bytes_per_feature, map_bytes=4):
+    """name -> (bound, algorithmic units per step).  Gather bytes keep SURVEY 8d's s = 4 B per map
+    element (the reference's fp32 maps) whatever the prepared maps' storage type: `achieved` is
+    algorithmic work per second, so halving the stored bytes shows up as a higher rate."""
     P = B * N
     from oracle import synth
     vox_elems = [int(np.prod(s)) for s in synth.vox_map_shapes(B, vox_res)]
@@ -128,9 +130,10 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
     def step(events=None):
         pre, arr = events if events else (None, None)
         if pre: ev.record(pre[0])
-        img = hip.prep_img_maps(inp["img_maps"], inp["map_size"])
+        md = hip.map_dtype_for(precision)
+        img = hip.prep_img_maps(inp["img_maps"], inp["map_size"], md)
         if pre: ev.record(pre[1])
-        vox = hip.prep_vox_maps(inp["vox_maps"])
+        vox = hip.prep_vox_maps(inp["vox_maps"], md)
         if pre: ev.record(pre[2])
         packed = hip.prep_mlp_weights(inp["weights"], vox.channels, img.channels, precision)
         if pre: ev.record(pre[3])
@@ -321,7 +324,9 @@ def main():
         "data": "synthetic",
         "config": {"workload": args.workload, "images_per_gpu": B, "points_per_image": N,
                    "global_points_per_step": world * P, "precision": headline,
-                   "mlp_arithmetic": arith[headline], "gather_arithmetic": "fp32 (fp32 maps)",
+                   "mlp_arithmetic": arith[headline],
+                   "gather_arithmetic": "fp32 interpolation; prepared maps stored as "
+                                        + ("fp16" if hip.map_dtype_for(headline) == "f16" else "fp32"),
                    "inputs": "reference layout (NCHW/NCDHW fp32) resident in HBM; layout hand-off + weight "
                              "repack inside the timed step",
                    "parallelism": f"batch-sharded x{world}" + (" + RCCL all-gather of sdf" if world > 1 else "")},

@@ -52,6 +52,13 @@ enum ListStatus {
  * The packed weights (list_prep_mlp_weights) are specific to {BF16X3,BF16} or {FP16}. */
 enum ListPrecision { LIST_PREC_BF16X3 = 0, LIST_PREC_BF16 = 1, LIST_PREC_FP16 = 2 };
 
+/* Element type of the PREPARED (channels-last) maps the gathers read.  F16 halves the bytes of the
+ * layout hand-off and of every tap (round-to-nearest-even, saturating at +-65504); interpolation is
+ * fp32 either way.  Meant to be paired with LIST_PREC_FP16, whose features are rounded to fp16 after
+ * interpolation anyway (measured |err| of the pair ~5e-5, inside the 1e-4 bound).  Needs every vector
+ * voxel level and the perceptual map to have a channel count that is a multiple of 8. */
+enum ListMapDtype { LIST_MAP_F32 = 0, LIST_MAP_F16 = 1 };
+
 /* One 2-D feature map [B,C,H,W] float32 with element strides (NCHW or channels-last). */
 typedef struct ListMap2D {
   const float* data;
@@ -68,8 +75,10 @@ typedef struct ListMap3D {
 
 /* A voxel level in the layout the gather kernels read: per image [D][H][W][C] contiguous. */
 typedef struct ListVoxLevel {
-  const float* data;
+  const void* data;          /* float or half elements, see dtype */
   int32_t C, D, H, W;
+  int32_t dtype;             /* enum ListMapDtype */
+  int32_t reserved_;
   int64_t image_stride;      /* elements between images */
 } ListVoxLevel;
 
@@ -92,19 +101,22 @@ typedef struct ListMlpWeights {
  * out[B][map_size][map_size][sum C_i] (channel order = concatenation order of modules.py:53).
  * Returns LIST_OK or an error.  Required out size: list_img_map_bytes().
  */
-size_t list_img_map_bytes(const ListMap2D maps[LIST_N_IMG_LEVELS], int32_t B, int32_t map_size);
+size_t list_img_map_bytes(const ListMap2D maps[LIST_N_IMG_LEVELS], int32_t B, int32_t map_size,
+                          int32_t map_dtype);
 int list_prep_img_maps(const ListMap2D maps[LIST_N_IMG_LEVELS], int32_t B, int32_t map_size,
-                       float* out, size_t out_bytes, void* stream);
+                       int32_t map_dtype, void* out, size_t out_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * list_prep_vox_maps -- layout hand-off for F.grid_sample 3-D (network/modules.py:263-265):
  * converts each [B,C,D,H,W] map to per-image [D][H][W][C].  A level that already has that
- * layout (channels_last_3d strides, or C == 1 with contiguous D,H,W) is used in place and
- * costs nothing.  levels_out[] (host memory) receives the descriptors for list_sdf_query_fwd.
+ * layout (channels_last_3d strides, or C == 1 with contiguous D,H,W) is used in place (as fp32)
+ * and costs nothing; converted levels are written in `map_dtype`.  levels_out[] (host memory)
+ * receives the descriptors for list_sdf_query_fwd.
  */
-size_t list_vox_pack_bytes(const ListMap3D maps[LIST_N_VOX_LEVELS], int32_t B);
-int list_prep_vox_maps(const ListMap3D maps[LIST_N_VOX_LEVELS], int32_t B, float* pack,
-                       size_t pack_bytes, ListVoxLevel levels_out[LIST_N_VOX_LEVELS], void* stream);
+size_t list_vox_pack_bytes(const ListMap3D maps[LIST_N_VOX_LEVELS], int32_t B, int32_t map_dtype);
+int list_prep_vox_maps(const ListMap3D maps[LIST_N_VOX_LEVELS], int32_t B, int32_t map_dtype,
+                       void* pack, size_t pack_bytes, ListVoxLevel levels_out[LIST_N_VOX_LEVELS],
+                       void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * list_prep_mlp_weights -- one-off repack of the Conv1d(k=1) parameters
@@ -127,7 +139,8 @@ typedef struct ListQueryArgs {
   int32_t perm[3];                      /* p[i] = scale * query[..., perm[i]]; {2,1,0}, 2.0 for */
   float scale;                          /*   raw queries (models.py:91-92); {0,1,2}, 1.0 if done */
   const float* trans_mat;               /* [B,4,3] contiguous (models.py:86) */
-  const float* img_map;                 /* output of list_prep_img_maps, or NULL with percep_feat */
+  const void* img_map;                  /* output of list_prep_img_maps, or NULL with percep_feat */
+  int32_t img_dtype;                    /* enum ListMapDtype of img_map */
   int32_t map_size;                     /* 137 */
   int32_t img_C;                        /* 1024 */
   float clamp_hi;                       /* 136.0 (hard-coded in modules.py:43) */
@@ -175,7 +188,7 @@ typedef struct ListPoolArgs {
   int32_t B, N;
   const float* pc; int64_t p_sb, p_sn, p_sc;   /* [B,N,3] (already permuted/scaled) */
   const float* trans_mat;                       /* [B,4,3] contiguous */
-  const float* img_map; int32_t map_size, img_C;
+  const void* img_map; int32_t img_dtype, map_size, img_C;
   float clamp_hi;
   float* out;                                   /* [B,img_C,N] contiguous */
 } ListPoolArgs;

@@ -42,11 +42,62 @@ __device__ __forceinline__ Axis axis_setup(float c, int size) {
   return a;
 }
 
-__device__ __forceinline__ float4 fma4(const float4& v, float w, const float4& a) {
-  return make_float4(fmaf(v.x, w, a.x), fmaf(v.y, w, a.y), fmaf(v.z, w, a.z), fmaf(v.w, w, a.w));
+// ---- map element formats -------------------------------------------------------------------------------
+// A lane owns V consecutive channels of a channels-last map: 4 floats (fp32 maps) or 8 halfs (fp16
+// maps); either way one 16-B load per tap.  All interpolation arithmetic is fp32.
+template <int F16> struct MapT;
+template <> struct MapT<0> {
+  static constexpr int V = 4;
+  using Raw = float4;
+  static __device__ __forceinline__ Raw load(const void* base, int64_t off) {
+    return *(const float4*)((const float*)base + off);
+  }
+  static __device__ __forceinline__ void unpack(const Raw& r, float (&f)[4]) {
+    f[0] = r.x; f[1] = r.y; f[2] = r.z; f[3] = r.w;
+  }
+};
+template <> struct MapT<1> {
+  static constexpr int V = 8;
+  using Raw = uint4;
+  static __device__ __forceinline__ Raw load(const void* base, int64_t off) {
+    return *(const uint4*)((const unsigned short*)base + off);
+  }
+  static __device__ __forceinline__ void unpack(const Raw& r, float (&f)[8]) {
+    f[0] = h2f((unsigned short)(r.x & 0xffff)); f[1] = h2f((unsigned short)(r.x >> 16));
+    f[2] = h2f((unsigned short)(r.y & 0xffff)); f[3] = h2f((unsigned short)(r.y >> 16));
+    f[4] = h2f((unsigned short)(r.z & 0xffff)); f[5] = h2f((unsigned short)(r.z >> 16));
+    f[6] = h2f((unsigned short)(r.w & 0xffff)); f[7] = h2f((unsigned short)(r.w >> 16));
+  }
+};
+
+template <typename M>
+__device__ __forceinline__ void tap_mul(const typename M::Raw& r, float w, float (&a)[M::V]) {
+  float f[M::V];
+  M::unpack(r, f);
+#pragma unroll
+  for (int c = 0; c < M::V; ++c) a[c] = f[c] * w;
+}
+template <typename M>
+__device__ __forceinline__ void tap_fma(const typename M::Raw& r, float w, float (&a)[M::V]) {
+  float f[M::V];
+  M::unpack(r, f);
+#pragma unroll
+  for (int c = 0; c < M::V; ++c) a[c] = fmaf(f[c], w, a[c]);
 }
 
-// The 8 taps of one trilinear sample: element offsets (relative to the image/channel-quad base) and
+// store V consecutive features of one row of X
+template <int FMT, int V>
+__device__ __forceinline__ void store_feats(unsigned short* __restrict__ xh, unsigned short* __restrict__ xl,
+                                            int64_t off, const float (&a)[V], bool valid) {
+#pragma unroll
+  for (int h = 0; h < V / 4; ++h) {
+    float4 v = valid ? make_float4(a[4 * h], a[4 * h + 1], a[4 * h + 2], a[4 * h + 3])
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    store_feat4<FMT>(xh, xl, off + 4 * h, v);
+  }
+}
+
+// The 8 taps of one trilinear sample: element offsets (relative to the image/channel base) and
 // weights in the accumulation order of the ATen CPU kernel: tnw tne tsw tse bnw bne bsw bse.
 struct Taps { int o[8]; float w[8]; };
 
@@ -68,11 +119,11 @@ __device__ __forceinline__ Taps make_taps(float x, float y, float z, int C, int 
   return t;
 }
 
-__device__ __forceinline__ float4 reduce_taps(const float4 (&v)[8], const Taps& t) {
-  float4 acc = make_float4(v[0].x * t.w[0], v[0].y * t.w[0], v[0].z * t.w[0], v[0].w * t.w[0]);
+template <typename M>
+__device__ __forceinline__ void reduce_taps(const typename M::Raw (&v)[8], const Taps& t, float (&acc)[M::V]) {
+  tap_mul<M>(v[0], t.w[0], acc);
 #pragma unroll
-  for (int k = 1; k < 8; ++k) acc = fma4(v[k], t.w[k], acc);
-  return acc;
+  for (int k = 1; k < 8; ++k) tap_fma<M>(v[k], t.w[k], acc);
 }
 
 // stencil point j of network/modules.py:205-214: centre, then (-d,+d) along x, y, z
@@ -85,60 +136,64 @@ __device__ __forceinline__ void stencil_point(const Pt& p, float& x, float& y, f
 
 // Two stencil points at a time: all 16 tap loads are issued before the first use, so a wave has
 // 16 KB in flight per step instead of one dependent 8-load round trip per stencil point.
-template <int C, int J0, int J1, int FMT>
-__device__ __forceinline__ void gather_pair(const ListVoxLevel& lv, const float* __restrict__ base,
-                                            const Pt& p, unsigned short* __restrict__ xh,
+template <int C, int J0, int J1, int FMT, typename M>
+__device__ __forceinline__ void gather_pair(const ListVoxLevel& lv, const void* __restrict__ base,
+                                            int64_t boff, const Pt& p, unsigned short* __restrict__ xh,
                                             unsigned short* __restrict__ xl, int64_t out_off) {
   float x0, y0, z0, x1, y1, z1;
   stencil_point<J0>(p, x0, y0, z0);
   stencil_point<J1>(p, x1, y1, z1);
   const Taps t0 = make_taps(x0, y0, z0, C, lv.D, lv.H, lv.W);
   const Taps t1 = make_taps(x1, y1, z1, C, lv.D, lv.H, lv.W);
-  float4 v0[8], v1[8];
+  typename M::Raw v0[8], v1[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) v0[k] = *(const float4*)(base + t0.o[k]);
+  for (int k = 0; k < 8; ++k) v0[k] = M::load(base, boff + t0.o[k]);
   if (J1 != J0) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v1[k] = *(const float4*)(base + t1.o[k]);
+    for (int k = 0; k < 8; ++k) v1[k] = M::load(base, boff + t1.o[k]);
   }
-  float4 r0 = reduce_taps(v0, t0);
-  if (!p.valid) r0 = make_float4(0.f, 0.f, 0.f, 0.f);
-  store_feat4<FMT>(xh, xl, out_off + J0 * C, r0);
+  float r[M::V];
+  reduce_taps<M>(v0, t0, r);
+  store_feats<FMT, M::V>(xh, xl, out_off + J0 * C, r, p.valid);
   if (J1 != J0) {
-    float4 r1 = reduce_taps(v1, t1);
-    if (!p.valid) r1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    store_feat4<FMT>(xh, xl, out_off + J1 * C, r1);
+    reduce_taps<M>(v1, t1, r);
+    store_feats<FMT, M::V>(xh, xl, out_off + J1 * C, r, p.valid);
   }
 }
 
-// grid = rows/RB, block = 256.  LP = C/4 lanes share a point; a wave covers 64/LP points.  The
+// grid = rows/RB, block = 256.  LP = C/V lanes share a point; a wave covers 64/LP points.  The
 // workgroup's points are fetched once, in parallel, into LDS (one dependent chain order -> query
 // per workgroup instead of one per iteration).
-template <int C, int FMT>
+template <int C, int V> struct VoxGeom {
+  static constexpr int LP = C / V;                                  // lanes per point
+  static constexpr int PW = 64 / LP;                                // points per wave per iteration
+  static constexpr int ITERS = (4 * PW >= kGatherRows) ? 1 : kGatherRows / (4 * PW);
+  static constexpr int RB = 4 * PW * ITERS;                         // rows per workgroup: 64, 128 or 256
+};
+
+template <int C, int FMT, int F16>
 __global__ __launch_bounds__(256) void k_gather_vox(GatherParams g, ListVoxLevel lv, int col_off) {
-  constexpr int LP = C / 4;              // lanes per point
-  constexpr int PW = 64 / LP;            // points per wave per iteration
-  constexpr int ITERS = (4 * PW >= kGatherRows) ? 1 : kGatherRows / (4 * PW);
-  constexpr int RB = 4 * PW * ITERS;     // rows per workgroup (64, 128 or 256: divides g.rows)
-  __shared__ Pt pts[RB];
+  using M = MapT<F16>;
+  using G = VoxGeom<C, M::V>;
+  __shared__ Pt pts[G::RB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int quad = lane % LP, psub = lane / LP;
+  const int sub = lane % G::LP, psub = lane / G::LP;
   const int blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
-  if (threadIdx.x < RB) pts[threadIdx.x] = load_point(g, blk * RB + threadIdx.x);
+  if (threadIdx.x < G::RB) pts[threadIdx.x] = load_point(g, blk * G::RB + threadIdx.x);
   __syncthreads();
   unsigned short* __restrict__ xh = g.x_hi;
   unsigned short* __restrict__ xl = g.x_lo;
 #pragma unroll 1
-  for (int it = 0; it < ITERS; ++it) {
-    const int local = it * (4 * PW) + wave * PW + psub;
-    const int row = blk * RB + local;
+  for (int it = 0; it < G::ITERS; ++it) {
+    const int local = it * (4 * G::PW) + wave * G::PW + psub;
+    const int row = blk * G::RB + local;
     const Pt p = pts[local];
-    const float* __restrict__ base = lv.data + (int64_t)p.b * lv.image_stride + quad * 4;
-    const int64_t out_off = (int64_t)row * g.Kp + col_off + quad * 4;
-    gather_pair<C, 0, 1, FMT>(lv, base, p, xh, xl, out_off);
-    gather_pair<C, 2, 3, FMT>(lv, base, p, xh, xl, out_off);
-    gather_pair<C, 4, 5, FMT>(lv, base, p, xh, xl, out_off);
-    gather_pair<C, 6, 6, FMT>(lv, base, p, xh, xl, out_off);
+    const int64_t boff = (int64_t)p.b * lv.image_stride + sub * M::V;
+    const int64_t out_off = (int64_t)row * g.Kp + col_off + sub * M::V;
+    gather_pair<C, 0, 1, FMT, M>(lv, lv.data, boff, p, xh, xl, out_off);
+    gather_pair<C, 2, 3, FMT, M>(lv, lv.data, boff, p, xh, xl, out_off);
+    gather_pair<C, 4, 5, FMT, M>(lv, lv.data, boff, p, xh, xl, out_off);
+    gather_pair<C, 6, 6, FMT, M>(lv, lv.data, boff, p, xh, xl, out_off);
   }
 }
 
@@ -150,8 +205,6 @@ __global__ __launch_bounds__(256) void k_gather_vox(GatherParams g, ListVoxLevel
 // are L1-bandwidth bound).  Each axis is factored: P[k] = sum over the centre's 2x2 of the other two
 // axes of plane k, then out_j = sum_k w_j[k] P[k] with the 4-entry weight vector of stencil point j
 // (two non-zeros).  Same taps and weights as the reference; only the summation order differs.
-struct Win { int i[4]; };     // the 4 plane indices c-1, c, c+1, c+2 clamped to [0, size-1]
-
 __device__ __forceinline__ void window_weights(const Axis& a, int cbase, float (&w)[4]) {
   // Axis a samples planes a.i0 and a.i0+1 (if has1); cbase = index of window slot 0
   const int k0 = a.i0 - cbase;            // 0, 1 or 2
@@ -159,34 +212,51 @@ __device__ __forceinline__ void window_weights(const Axis& a, int cbase, float (
   for (int k = 0; k < 4; ++k) w[k] = (k == k0) ? a.w0 : ((k == k0 + 1 && a.has1) ? a.w1 : 0.f);
 }
 
-__device__ __forceinline__ float4 wsum4(const float4 (&P)[4], const float (&w)[4]) {
-  float4 r = make_float4(P[0].x * w[0], P[0].y * w[0], P[0].z * w[0], P[0].w * w[0]);
-  r = fma4(P[1], w[1], r); r = fma4(P[2], w[2], r); r = fma4(P[3], w[3], r);
-  return r;
+// plane value: sum of 4 taps with the centre 2x2 weights of the other two axes
+template <typename M>
+__device__ __forceinline__ void plane4(const typename M::Raw& a, const typename M::Raw& b,
+                                       const typename M::Raw& c, const typename M::Raw& d,
+                                       const float (&w)[4], float (&P)[M::V]) {
+  tap_mul<M>(a, w[0], P); tap_fma<M>(b, w[1], P); tap_fma<M>(c, w[2], P); tap_fma<M>(d, w[3], P);
 }
 
-template <int C, int FMT>
+template <int FMT, int V>
+__device__ __forceinline__ void store_wsum(const float (&P)[4][V], const float (&w)[4],
+                                           unsigned short* __restrict__ xh, unsigned short* __restrict__ xl,
+                                           int64_t off, bool valid) {
+  float r[V];
+#pragma unroll
+  for (int c = 0; c < V; ++c) {
+    float t = P[0][c] * w[0];
+    t = fmaf(P[1][c], w[1], t); t = fmaf(P[2][c], w[2], t); t = fmaf(P[3][c], w[3], t);
+    r[c] = t;
+  }
+  store_feats<FMT, V>(xh, xl, off, r, valid);
+}
+
+template <int C, int FMT, int F16>
 __global__ __launch_bounds__(256) void k_gather_vox_near(GatherParams g, ListVoxLevel lv, int col_off) {
-  constexpr int LP = C / 4;
-  constexpr int PW = 64 / LP;
-  constexpr int ITERS = (4 * PW >= kGatherRows) ? 1 : kGatherRows / (4 * PW);
-  constexpr int RB = 4 * PW * ITERS;
-  __shared__ Pt pts[RB];
+  using M = MapT<F16>;
+  using G = VoxGeom<C, M::V>;
+  using Raw = typename M::Raw;
+  constexpr int V = M::V;
+  __shared__ Pt pts[G::RB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int quad = lane % LP, psub = lane / LP;
+  const int sub = lane % G::LP, psub = lane / G::LP;
   const int blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
-  if (threadIdx.x < RB) pts[threadIdx.x] = load_point(g, blk * RB + threadIdx.x);
+  if (threadIdx.x < G::RB) pts[threadIdx.x] = load_point(g, blk * G::RB + threadIdx.x);
   __syncthreads();
   unsigned short* __restrict__ xh = g.x_hi;
   unsigned short* __restrict__ xl = g.x_lo;
   const int W = lv.W, H = lv.H, D = lv.D;
 #pragma unroll 1
-  for (int it = 0; it < ITERS; ++it) {
-    const int local = it * (4 * PW) + wave * PW + psub;
-    const int row = blk * RB + local;
+  for (int it = 0; it < G::ITERS; ++it) {
+    const int local = it * (4 * G::PW) + wave * G::PW + psub;
+    const int row = blk * G::RB + local;
     const Pt p = pts[local];
-    const float* __restrict__ base = lv.data + (int64_t)p.b * lv.image_stride + quad * 4;
-    const int64_t out_off = (int64_t)row * g.Kp + col_off + quad * 4;
+    const void* __restrict__ base = lv.data;
+    const int64_t bo = (int64_t)p.b * lv.image_stride + sub * V;
+    const int64_t out_off = (int64_t)row * g.Kp + col_off + sub * V;
 
     const Axis cx = axis_setup(p.x, W), cy = axis_setup(p.y, H), cz = axis_setup(p.z, D);
     const Axis mx = axis_setup(p.x - kDisp, W), px = axis_setup(p.x + kDisp, W);
@@ -210,78 +280,50 @@ __global__ __launch_bounds__(256) void k_gather_vox_near(GatherParams g, ListVox
     const float wxz[4] = {wcx[1] * wcz[1], wcx[2] * wcz[1], wcx[1] * wcz[2], wcx[2] * wcz[2]};
     const float wxy[4] = {wcx[1] * wcy[1], wcx[2] * wcy[1], wcx[1] * wcy[2], wcx[2] * wcy[2]};
 
-    // phase 1: 4 x-planes x centre (y,z) 2x2 -> stencil points 0, 1, 2
-    float4 A[4][4];
+    // 4 x-planes x centre (y,z) 2x2: A[k][0..3] = (z1,y1) (z1,y2) (z2,y1) (z2,y2) of x-plane k
+    Raw A[4][4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      A[k][0] = *(const float4*)(base + oz[1] + oy[1] + ox[k]);
-      A[k][1] = *(const float4*)(base + oz[1] + oy[2] + ox[k]);
-      A[k][2] = *(const float4*)(base + oz[2] + oy[1] + ox[k]);
-      A[k][3] = *(const float4*)(base + oz[2] + oy[2] + ox[k]);
+      A[k][0] = M::load(base, bo + oz[1] + oy[1] + ox[k]);
+      A[k][1] = M::load(base, bo + oz[1] + oy[2] + ox[k]);
+      A[k][2] = M::load(base, bo + oz[2] + oy[1] + ox[k]);
+      A[k][3] = M::load(base, bo + oz[2] + oy[2] + ox[k]);
     }
-    // phase 2/3 loads: the two extra y-planes and z-planes over the centre 2x2 of the other axes
-    float4 By[2][4], Bz[2][4];
+    // the two extra y-planes and z-planes over the centre 2x2 of the other two axes
+    Raw By[2][4], Bz[2][4];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      const int ky = e ? 3 : 0, kz = e ? 3 : 0;
-      By[e][0] = *(const float4*)(base + oz[1] + oy[ky] + ox[1]);
-      By[e][1] = *(const float4*)(base + oz[1] + oy[ky] + ox[2]);
-      By[e][2] = *(const float4*)(base + oz[2] + oy[ky] + ox[1]);
-      By[e][3] = *(const float4*)(base + oz[2] + oy[ky] + ox[2]);
-      Bz[e][0] = *(const float4*)(base + oz[kz] + oy[1] + ox[1]);
-      Bz[e][1] = *(const float4*)(base + oz[kz] + oy[1] + ox[2]);
-      Bz[e][2] = *(const float4*)(base + oz[kz] + oy[2] + ox[1]);
-      Bz[e][3] = *(const float4*)(base + oz[kz] + oy[2] + ox[2]);
+      const int ke = e ? 3 : 0;
+      By[e][0] = M::load(base, bo + oz[1] + oy[ke] + ox[1]);
+      By[e][1] = M::load(base, bo + oz[1] + oy[ke] + ox[2]);
+      By[e][2] = M::load(base, bo + oz[2] + oy[ke] + ox[1]);
+      By[e][3] = M::load(base, bo + oz[2] + oy[ke] + ox[2]);
+      Bz[e][0] = M::load(base, bo + oz[ke] + oy[1] + ox[1]);
+      Bz[e][1] = M::load(base, bo + oz[ke] + oy[1] + ox[2]);
+      Bz[e][2] = M::load(base, bo + oz[ke] + oy[2] + ox[1]);
+      Bz[e][3] = M::load(base, bo + oz[ke] + oy[2] + ox[2]);
     }
-    float4 P[4];
-    float4 out[7];
-    // x axis
+    float P[4][V];
+    // x axis -> stencil points 0, 1, 2
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float4 r = make_float4(A[k][0].x * wyz[0], A[k][0].y * wyz[0], A[k][0].z * wyz[0], A[k][0].w * wyz[0]);
-      r = fma4(A[k][1], wyz[1], r); r = fma4(A[k][2], wyz[2], r); r = fma4(A[k][3], wyz[3], r);
-      P[k] = r;
-    }
-    out[0] = wsum4(P, wcx); out[1] = wsum4(P, wmx); out[2] = wsum4(P, wpx);
-    // y axis: planes 1,2 come from A (x = slots 1,2), planes 0,3 from By
-    {
-      float4 r;
-      r = make_float4(By[0][0].x * wxz[0], By[0][0].y * wxz[0], By[0][0].z * wxz[0], By[0][0].w * wxz[0]);
-      r = fma4(By[0][1], wxz[1], r); r = fma4(By[0][2], wxz[2], r); r = fma4(By[0][3], wxz[3], r);
-      P[0] = r;
-      r = make_float4(A[1][0].x * wxz[0], A[1][0].y * wxz[0], A[1][0].z * wxz[0], A[1][0].w * wxz[0]);
-      r = fma4(A[2][0], wxz[1], r); r = fma4(A[1][2], wxz[2], r); r = fma4(A[2][2], wxz[3], r);
-      P[1] = r;
-      r = make_float4(A[1][1].x * wxz[0], A[1][1].y * wxz[0], A[1][1].z * wxz[0], A[1][1].w * wxz[0]);
-      r = fma4(A[2][1], wxz[1], r); r = fma4(A[1][3], wxz[2], r); r = fma4(A[2][3], wxz[3], r);
-      P[2] = r;
-      r = make_float4(By[1][0].x * wxz[0], By[1][0].y * wxz[0], By[1][0].z * wxz[0], By[1][0].w * wxz[0]);
-      r = fma4(By[1][1], wxz[1], r); r = fma4(By[1][2], wxz[2], r); r = fma4(By[1][3], wxz[3], r);
-      P[3] = r;
-    }
-    out[3] = wsum4(P, wmy); out[4] = wsum4(P, wpy);
-    // z axis: planes 1,2 from A, planes 0,3 from Bz
-    {
-      float4 r;
-      r = make_float4(Bz[0][0].x * wxy[0], Bz[0][0].y * wxy[0], Bz[0][0].z * wxy[0], Bz[0][0].w * wxy[0]);
-      r = fma4(Bz[0][1], wxy[1], r); r = fma4(Bz[0][2], wxy[2], r); r = fma4(Bz[0][3], wxy[3], r);
-      P[0] = r;
-      r = make_float4(A[1][0].x * wxy[0], A[1][0].y * wxy[0], A[1][0].z * wxy[0], A[1][0].w * wxy[0]);
-      r = fma4(A[2][0], wxy[1], r); r = fma4(A[1][1], wxy[2], r); r = fma4(A[2][1], wxy[3], r);
-      P[1] = r;
-      r = make_float4(A[1][2].x * wxy[0], A[1][2].y * wxy[0], A[1][2].z * wxy[0], A[1][2].w * wxy[0]);
-      r = fma4(A[2][2], wxy[1], r); r = fma4(A[1][3], wxy[2], r); r = fma4(A[2][3], wxy[3], r);
-      P[2] = r;
-      r = make_float4(Bz[1][0].x * wxy[0], Bz[1][0].y * wxy[0], Bz[1][0].z * wxy[0], Bz[1][0].w * wxy[0]);
-      r = fma4(Bz[1][1], wxy[1], r); r = fma4(Bz[1][2], wxy[2], r); r = fma4(Bz[1][3], wxy[3], r);
-      P[3] = r;
-    }
-    out[5] = wsum4(P, wmz); out[6] = wsum4(P, wpz);
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {
-      if (!p.valid) out[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      store_feat4<FMT>(xh, xl, out_off + j * C, out[j]);
-    }
+    for (int k = 0; k < 4; ++k) plane4<M>(A[k][0], A[k][1], A[k][2], A[k][3], wyz, P[k]);
+    store_wsum<FMT, V>(P, wcx, xh, xl, out_off + 0 * C, p.valid);
+    store_wsum<FMT, V>(P, wmx, xh, xl, out_off + 1 * C, p.valid);
+    store_wsum<FMT, V>(P, wpx, xh, xl, out_off + 2 * C, p.valid);
+    // y axis: planes 1,2 come from A (x slots 1,2), planes 0,3 from By; weights (x1,z1)(x2,z1)(x1,z2)(x2,z2)
+    plane4<M>(By[0][0], By[0][1], By[0][2], By[0][3], wxz, P[0]);
+    plane4<M>(A[1][0], A[2][0], A[1][2], A[2][2], wxz, P[1]);
+    plane4<M>(A[1][1], A[2][1], A[1][3], A[2][3], wxz, P[2]);
+    plane4<M>(By[1][0], By[1][1], By[1][2], By[1][3], wxz, P[3]);
+    store_wsum<FMT, V>(P, wmy, xh, xl, out_off + 3 * C, p.valid);
+    store_wsum<FMT, V>(P, wpy, xh, xl, out_off + 4 * C, p.valid);
+    // z axis: planes 1,2 from A, planes 0,3 from Bz; weights (x1,y1)(x2,y1)(x1,y2)(x2,y2)
+    plane4<M>(Bz[0][0], Bz[0][1], Bz[0][2], Bz[0][3], wxy, P[0]);
+    plane4<M>(A[1][0], A[2][0], A[1][1], A[2][1], wxy, P[1]);
+    plane4<M>(A[1][2], A[2][2], A[1][3], A[2][3], wxy, P[2]);
+    plane4<M>(Bz[1][0], Bz[1][1], Bz[1][2], Bz[1][3], wxy, P[3]);
+    store_wsum<FMT, V>(P, wmz, xh, xl, out_off + 5 * C, p.valid);
+    store_wsum<FMT, V>(P, wpz, xh, xl, out_off + 6 * C, p.valid);
   }
 }
 
@@ -317,18 +359,6 @@ __device__ __forceinline__ Proj project(const float* __restrict__ T, float px, f
   r.o10 = (y1 * ms + x0) * Ct; r.o11 = (y1 * ms + x1) * Ct;
   r.w00 = wx0 * wy0; r.w01 = wx1 * wy0; r.w10 = wx0 * wy1; r.w11 = wx1 * wy1;
   return r;
-}
-
-__device__ __forceinline__ float4 bilinear4(const float* __restrict__ img, const Proj& pr) {
-  const float4 v00 = *(const float4*)(img + pr.o00);
-  const float4 v01 = *(const float4*)(img + pr.o01);
-  const float4 v10 = *(const float4*)(img + pr.o10);
-  const float4 v11 = *(const float4*)(img + pr.o11);
-  float4 acc = make_float4(v00.x * pr.w00, v00.y * pr.w00, v00.z * pr.w00, v00.w * pr.w00);
-  acc = fma4(v01, pr.w01, acc);
-  acc = fma4(v10, pr.w10, acc);
-  acc = fma4(v11, pr.w11, acc);
-  return acc;
 }
 
 // ---- ordering of the query points ---------------------------------------------------------------------
@@ -466,12 +496,13 @@ hipError_t launch_sort_points(const GatherParams& g, const ListQueryArgs& a, con
 // -> trans_mat per workgroup), then two points (8 x 16-B loads per lane) are in flight per step.
 struct ImgPoint { Proj pr; int row; int b; int valid; };
 
-template <int FMT>
-__global__ __launch_bounds__(256) void k_gather_img(GatherParams g, const float* __restrict__ img_map,
+template <int FMT, int F16>
+__global__ __launch_bounds__(256) void k_gather_img(GatherParams g, const void* __restrict__ img_map,
                                                     const float* __restrict__ trans_mat, int ms,
                                                     int Ct, float clamp_hi, int col_off) {
+  using M = MapT<F16>;
+  using Raw = typename M::Raw;
   __shared__ ImgPoint ipt[kGatherRows];
-  const int nq = Ct / 4;
   const int blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
   if (threadIdx.x < kGatherRows) {
     int row = blk * kGatherRows + threadIdx.x;
@@ -499,29 +530,33 @@ __global__ __launch_bounds__(256) void k_gather_img(GatherParams g, const float*
   unsigned short* __restrict__ xh = g.x_hi;
   unsigned short* __restrict__ xl = g.x_lo;
   const int64_t img_stride = (int64_t)ms * ms * Ct;
-#ifndef LIST_IMG_PTS
-#define LIST_IMG_PTS 2
-#endif
-  constexpr int NP = LIST_IMG_PTS;      // points in flight per step: 4 * NP 16-B loads per lane
+  constexpr int NP = 2;                 // points in flight per lane: 4 * NP 16-B loads (measured best)
+  const int lq = Ct / M::V;             // lanes that cover one point
+  // a step covers `span` points: the workgroup's 256 lanes over (point, channel group), NP deep
+  const int ppp = lq >= 256 ? 1 : 256 / lq;                 // points per pass of the workgroup
+  const int span = ppp * NP;
 #pragma unroll 1
-  for (int i = 0; i < kGatherRows; i += NP) {
-    for (int q = threadIdx.x; q < nq; q += 256) {
-      float4 v[NP][4];
+  for (int i = 0; i < kGatherRows; i += span) {
+    for (int u = threadIdx.x; u < ppp * lq; u += 256) {
+      const int pp = u / lq, q = u - pp * lq;
+      Raw v[NP][4];
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
-        const ImgPoint& a = ipt[i + k];
-        const float* __restrict__ ia = img_map + a.b * img_stride + q * 4;
-        v[k][0] = *(const float4*)(ia + a.pr.o00); v[k][1] = *(const float4*)(ia + a.pr.o01);
-        v[k][2] = *(const float4*)(ia + a.pr.o10); v[k][3] = *(const float4*)(ia + a.pr.o11);
+        const int pi = min(i + k * ppp + pp, kGatherRows - 1);
+        const ImgPoint& a = ipt[pi];
+        const int64_t bo = a.b * img_stride + q * M::V;
+        v[k][0] = M::load(img_map, bo + a.pr.o00); v[k][1] = M::load(img_map, bo + a.pr.o01);
+        v[k][2] = M::load(img_map, bo + a.pr.o10); v[k][3] = M::load(img_map, bo + a.pr.o11);
       }
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
-        const ImgPoint& a = ipt[i + k];
-        float4 r = make_float4(v[k][0].x * a.pr.w00, v[k][0].y * a.pr.w00, v[k][0].z * a.pr.w00,
-                               v[k][0].w * a.pr.w00);
-        r = fma4(v[k][1], a.pr.w01, r); r = fma4(v[k][2], a.pr.w10, r); r = fma4(v[k][3], a.pr.w11, r);
-        if (!a.valid) r = make_float4(0.f, 0.f, 0.f, 0.f);
-        store_feat4<FMT>(xh, xl, (int64_t)a.row * g.Kp + col_off + q * 4, r);
+        const int pi = i + k * ppp + pp;
+        if (pi >= kGatherRows) continue;
+        const ImgPoint& a = ipt[pi];
+        float r[M::V];
+        tap_mul<M>(v[k][0], a.pr.w00, r); tap_fma<M>(v[k][1], a.pr.w01, r);
+        tap_fma<M>(v[k][2], a.pr.w10, r); tap_fma<M>(v[k][3], a.pr.w11, r);
+        store_feats<FMT, M::V>(xh, xl, (int64_t)a.row * g.Kp + col_off + q * M::V, r, a.valid != 0);
       }
     }
   }
@@ -573,7 +608,7 @@ __global__ __launch_bounds__(256) void k_gather_tail(GatherParams g, TailLevels 
   const int64_t ro = (int64_t)row * g.Kp;
   for (int l = 0; l < tl.n; ++l) {
     const ListVoxLevel& lv = tl.lv[l];
-    const float* __restrict__ base = lv.data + (int64_t)p.b * lv.image_stride;
+    const float* __restrict__ base = (const float*)lv.data + (int64_t)p.b * lv.image_stride;
     Taps t[LIST_N_STENCIL];
     float v[LIST_N_STENCIL][8];
 #pragma unroll
@@ -599,18 +634,27 @@ __global__ __launch_bounds__(256) void k_gather_tail(GatherParams g, TailLevels 
 }
 
 // ---- launch ----------------------------------------------------------------------------------------
-template <int C, int FMT>
-static hipError_t launch_vox_level(const GatherParams& g, const ListVoxLevel& lv, int col_off,
-                                   hipStream_t s) {
-  constexpr int PW = 64 / (C / 4);
-  constexpr int RB = (4 * PW >= kGatherRows) ? 4 * PW : kGatherRows;
+template <int C, int FMT, int F16>
+static hipError_t launch_vox_level_t(const GatherParams& g, const ListVoxLevel& lv, int col_off,
+                                     hipStream_t s) {
+  using G = VoxGeom<C, MapT<F16>::V>;
   const int big = lv.W > lv.H ? (lv.W > lv.D ? lv.W : lv.D) : (lv.H > lv.D ? lv.H : lv.D);
   const bool near = kDisp * 0.5f * (float)(big - 1) < 0.99f && C >= 16;   // stencil stays within one cell
   if (near)
-    hipLaunchKernelGGL((k_gather_vox_near<C, FMT>), dim3(g.rows / RB), dim3(256), 0, s, g, lv, col_off);
+    hipLaunchKernelGGL((k_gather_vox_near<C, FMT, F16>), dim3(g.rows / G::RB), dim3(256), 0, s, g, lv, col_off);
   else
-    hipLaunchKernelGGL((k_gather_vox<C, FMT>), dim3(g.rows / RB), dim3(256), 0, s, g, lv, col_off);
+    hipLaunchKernelGGL((k_gather_vox<C, FMT, F16>), dim3(g.rows / G::RB), dim3(256), 0, s, g, lv, col_off);
   return hipGetLastError();
+}
+
+template <int C, int FMT>
+static hipError_t launch_vox_level(const GatherParams& g, const ListVoxLevel& lv, int col_off,
+                                   hipStream_t s) {
+  if (lv.dtype == LIST_MAP_F16) {
+    if constexpr (C >= 8) return launch_vox_level_t<C, FMT, 1>(g, lv, col_off, s);
+    else return hipErrorInvalidValue;
+  }
+  return launch_vox_level_t<C, FMT, 0>(g, lv, col_off, s);
 }
 
 template <int FMT>
@@ -644,8 +688,11 @@ static hipError_t launch_gather_fmt(const GatherParams& g, const FeatLayout& L, 
   if (a.percep_feat) {
     hipLaunchKernelGGL(k_copy_percep<FMT>, dim3((g.rows + 255) / 256), dim3(256), 0, s, g,
                        a.percep_feat, a.pf_sb, a.pf_sc, a.pf_sn, L.img_C, L.img_off);
+  } else if (a.img_dtype == LIST_MAP_F16) {
+    hipLaunchKernelGGL((k_gather_img<FMT, 1>), dim3(g.rows / kGatherRows), dim3(256), 0, s, g, a.img_map,
+                       a.trans_mat, a.map_size, L.img_C, a.clamp_hi, L.img_off);
   } else {
-    hipLaunchKernelGGL(k_gather_img<FMT>, dim3(g.rows / kGatherRows), dim3(256), 0, s, g, a.img_map,
+    hipLaunchKernelGGL((k_gather_img<FMT, 0>), dim3(g.rows / kGatherRows), dim3(256), 0, s, g, a.img_map,
                        a.trans_mat, a.map_size, L.img_C, a.clamp_hi, L.img_off);
   }
   e = hipGetLastError();
@@ -688,8 +735,10 @@ hipError_t launch_features_out(const GatherParams& g, const FeatLayout& L, float
 }
 
 // ---- PerceptualPooling.forward alone: out[B][Ct][N] ---------------------------------------------------
-// lanes over points (coalesced writes along N), loop over channel quads.
+// lanes over points (coalesced writes along N), loop over channel groups.
+template <int F16>
 __global__ __launch_bounds__(256) void k_percep_pool(ListPoolArgs a) {
+  using M = MapT<F16>;
   const int64_t gp = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (gp >= (int64_t)a.B * a.N) return;
   const int b = (int)(gp / a.N);
@@ -697,20 +746,25 @@ __global__ __launch_bounds__(256) void k_percep_pool(ListPoolArgs a) {
   const float* q = a.pc + (int64_t)b * a.p_sb + (int64_t)n * a.p_sn;
   const Proj pr = project(a.trans_mat + b * 12, q[0], q[a.p_sc], q[2 * a.p_sc], a.map_size,
                           a.img_C, a.clamp_hi);
-  const float* img = a.img_map + (int64_t)b * a.map_size * a.map_size * a.img_C;
+  const int64_t bo = (int64_t)b * a.map_size * a.map_size * a.img_C;
   float* o = a.out + (int64_t)b * a.img_C * a.N + n;
-  for (int c = 0; c < a.img_C; c += 4) {
-    const float4 v = bilinear4(img + c, pr);
-    o[(int64_t)c * a.N] = v.x;
-    o[(int64_t)(c + 1) * a.N] = v.y;
-    o[(int64_t)(c + 2) * a.N] = v.z;
-    o[(int64_t)(c + 3) * a.N] = v.w;
+  for (int c = 0; c < a.img_C; c += M::V) {
+    float r[M::V];
+    tap_mul<M>(M::load(a.img_map, bo + pr.o00 + c), pr.w00, r);
+    tap_fma<M>(M::load(a.img_map, bo + pr.o01 + c), pr.w01, r);
+    tap_fma<M>(M::load(a.img_map, bo + pr.o10 + c), pr.w10, r);
+    tap_fma<M>(M::load(a.img_map, bo + pr.o11 + c), pr.w11, r);
+#pragma unroll
+    for (int k = 0; k < M::V; ++k) o[(int64_t)(c + k) * a.N] = r[k];
   }
 }
 
 hipError_t launch_percep_pool(const ListPoolArgs& a, hipStream_t s) {
   const int64_t P = (int64_t)a.B * a.N;
-  hipLaunchKernelGGL(k_percep_pool, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, a);
+  if (a.img_dtype == LIST_MAP_F16)
+    hipLaunchKernelGGL(k_percep_pool<1>, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(k_percep_pool<0>, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

@@ -30,7 +30,7 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 bool vox_in_place(const ListMap3D& m, ListVoxLevel* lv) {
   const int64_t C = m.C, W = m.W, H = m.H;
-  lv->C = m.C; lv->D = m.D; lv->H = m.H; lv->W = m.W;
+  lv->C = m.C; lv->D = m.D; lv->H = m.H; lv->W = m.W; lv->dtype = LIST_MAP_F32; lv->reserved_ = 0;
   if (m.C == 1) {
     if (m.sw == 1 && m.sh == W && m.sd == H * W) { lv->data = m.data; lv->image_stride = m.sb; return true; }
     return false;
@@ -55,8 +55,12 @@ int check_query_common(const ListQueryArgs* a, FeatLayout* L) {
       return fail(LIST_ERR_SHAPE, "voxel level %d: bad descriptor", l);
     if ((int64_t)v.D * v.H * v.W * v.C >= (int64_t)1 << 31)
       return fail(LIST_ERR_SHAPE, "voxel level %d: image larger than 2^31 elements", l);
-    if (v.C != 1 && (!aligned16(v.data) || (v.image_stride % 4) != 0))
+    if (v.dtype != LIST_MAP_F32 && v.dtype != LIST_MAP_F16)
+      return fail(LIST_ERR_ARG, "voxel level %d: dtype=%d", l, v.dtype);
+    if (v.C != 1 && (!aligned16(v.data) || (v.image_stride % (v.dtype == LIST_MAP_F16 ? 8 : 4)) != 0))
       return fail(LIST_ERR_SHAPE, "voxel level %d: data must be 16-byte aligned", l);
+    if (v.dtype == LIST_MAP_F16 && (v.C == 1 || v.C % 8 != 0))
+      return fail(LIST_ERR_UNSUPPORTED, "voxel level %d: fp16 maps need C %% 8 == 0 (C=%d)", l, v.C);
     if (v.C != 1 && (v.C > 256 || (v.C & (v.C - 1)) != 0 || v.C < 4))
       return fail(LIST_ERR_UNSUPPORTED, "voxel level %d: C=%d (need 1 or a power of two in 4..256)", l, v.C);
     vc[l] = v.C;
@@ -65,6 +69,10 @@ int check_query_common(const ListQueryArgs* a, FeatLayout* L) {
   if (a->percep_feat == nullptr) {
     if (!a->img_map || !a->trans_mat) return fail(LIST_ERR_ARG, "img_map/trans_mat is NULL");
     if (!aligned16(a->img_map)) return fail(LIST_ERR_SHAPE, "img_map must be 16-byte aligned");
+    if (a->img_dtype != LIST_MAP_F32 && a->img_dtype != LIST_MAP_F16)
+      return fail(LIST_ERR_ARG, "img_dtype=%d", a->img_dtype);
+    if (a->img_dtype == LIST_MAP_F16 && a->img_C % 8)
+      return fail(LIST_ERR_UNSUPPORTED, "fp16 image map needs img_C %% 8 == 0");
     if (a->map_size < 2) return fail(LIST_ERR_SHAPE, "map_size=%d", a->map_size);
     if ((int64_t)a->map_size * a->map_size * a->img_C >= (int64_t)1 << 31)
       return fail(LIST_ERR_SHAPE, "image map larger than 2^31 elements");
@@ -107,16 +115,21 @@ const char* list_last_error(void) { return g_err; }
 int list_abi_version(void) { return LIST_ABI_VERSION; }
 
 // ------------------------------------------------------------------------------------------ 2-D maps
-size_t list_img_map_bytes(const ListMap2D maps[LIST_N_IMG_LEVELS], int32_t B, int32_t map_size) {
-  if (!maps || B <= 0 || map_size <= 0) return 0;
+static bool dtype_ok(int32_t d) { return d == LIST_MAP_F32 || d == LIST_MAP_F16; }
+static size_t elem_bytes(int32_t d) { return d == LIST_MAP_F16 ? 2 : 4; }
+
+size_t list_img_map_bytes(const ListMap2D maps[LIST_N_IMG_LEVELS], int32_t B, int32_t map_size,
+                          int32_t map_dtype) {
+  if (!maps || B <= 0 || map_size <= 0 || !dtype_ok(map_dtype)) return 0;
   size_t Ct = 0;
   for (int i = 0; i < LIST_N_IMG_LEVELS; ++i) Ct += (size_t)maps[i].C;
-  return (size_t)B * map_size * map_size * Ct * sizeof(float);
+  return (size_t)B * map_size * map_size * Ct * elem_bytes(map_dtype);
 }
 
 int list_prep_img_maps(const ListMap2D maps[LIST_N_IMG_LEVELS], int32_t B, int32_t map_size,
-                       float* out, size_t out_bytes, void* stream) {
+                       int32_t map_dtype, void* out, size_t out_bytes, void* stream) {
   if (!maps || !out) return fail(LIST_ERR_ARG, "maps/out is NULL");
+  if (!dtype_ok(map_dtype)) return fail(LIST_ERR_ARG, "map_dtype=%d", map_dtype);
   if (B <= 0 || map_size < 2 || map_size > 320)
     return fail(LIST_ERR_SHAPE, "B=%d map_size=%d (need 2..320)", B, map_size);
   int Ct = 0;
@@ -126,33 +139,42 @@ int list_prep_img_maps(const ListMap2D maps[LIST_N_IMG_LEVELS], int32_t B, int32
       return fail(LIST_ERR_SHAPE, "image level %d: bad descriptor", i);
     Ct += m.C;
   }
-  if (Ct % 4) return fail(LIST_ERR_UNSUPPORTED, "total image channels %d not a multiple of 4", Ct);
-  if (out_bytes < list_img_map_bytes(maps, B, map_size))
+  const int align = map_dtype == LIST_MAP_F16 ? 8 : 4;
+  if (Ct % align) return fail(LIST_ERR_UNSUPPORTED, "total image channels %d not a multiple of %d", Ct, align);
+  if (!aligned16(out)) return fail(LIST_ERR_SHAPE, "out must be 16-byte aligned");
+  if (out_bytes < list_img_map_bytes(maps, B, map_size, map_dtype))
     return fail(LIST_ERR_WORKSPACE, "out buffer too small: %zu < %zu", out_bytes,
-                list_img_map_bytes(maps, B, map_size));
+                list_img_map_bytes(maps, B, map_size, map_dtype));
   if ((int64_t)B * map_size > 2147483647LL) return fail(LIST_ERR_SHAPE, "grid too large");
-  hipError_t e = launch_prep_img(maps, B, map_size, Ct, out, (hipStream_t)stream);
+  hipError_t e = launch_prep_img(maps, B, map_size, Ct, map_dtype == LIST_MAP_F16, out, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "prep_img launch");
   return LIST_OK;
 }
 
 // ------------------------------------------------------------------------------------------ 3-D maps
-size_t list_vox_pack_bytes(const ListMap3D maps[LIST_N_VOX_LEVELS], int32_t B) {
-  if (!maps || B <= 0) return 0;
+static bool level_as_f16(const ListMap3D& m, int32_t map_dtype) {
+  return map_dtype == LIST_MAP_F16 && m.C != 1 && (m.C % 8) == 0;
+}
+
+size_t list_vox_pack_bytes(const ListMap3D maps[LIST_N_VOX_LEVELS], int32_t B, int32_t map_dtype) {
+  if (!maps || B <= 0 || !dtype_ok(map_dtype)) return 0;
   size_t total = 0;
   for (int l = 0; l < LIST_N_VOX_LEVELS; ++l) {
     ListVoxLevel lv;
     if (vox_in_place(maps[l], &lv)) continue;
-    total += align_up((size_t)B * maps[l].C * maps[l].D * maps[l].H * maps[l].W * sizeof(float), 256);
+    total += align_up((size_t)B * maps[l].C * maps[l].D * maps[l].H * maps[l].W *
+                      (level_as_f16(maps[l], map_dtype) ? 2 : 4), 256);
   }
   return total;
 }
 
-int list_prep_vox_maps(const ListMap3D maps[LIST_N_VOX_LEVELS], int32_t B, float* pack,
-                       size_t pack_bytes, ListVoxLevel levels_out[LIST_N_VOX_LEVELS], void* stream) {
+int list_prep_vox_maps(const ListMap3D maps[LIST_N_VOX_LEVELS], int32_t B, int32_t map_dtype,
+                       void* pack, size_t pack_bytes, ListVoxLevel levels_out[LIST_N_VOX_LEVELS],
+                       void* stream) {
   if (!maps || !levels_out) return fail(LIST_ERR_ARG, "maps/levels_out is NULL");
+  if (!dtype_ok(map_dtype)) return fail(LIST_ERR_ARG, "map_dtype=%d", map_dtype);
   if (B <= 0 || B > 65535) return fail(LIST_ERR_SHAPE, "B=%d", B);
-  const size_t need = list_vox_pack_bytes(maps, B);
+  const size_t need = list_vox_pack_bytes(maps, B, map_dtype);
   if (need > 0 && (!pack || pack_bytes < need))
     return fail(LIST_ERR_WORKSPACE, "pack buffer too small: %zu < %zu", pack_bytes, need);
   if (need > 0 && !aligned16(pack)) return fail(LIST_ERR_SHAPE, "pack must be 16-byte aligned");
@@ -164,13 +186,15 @@ int list_prep_vox_maps(const ListMap3D maps[LIST_N_VOX_LEVELS], int32_t B, float
     if ((int64_t)m.D * m.H * m.W * m.C >= (int64_t)1 << 31)
       return fail(LIST_ERR_SHAPE, "voxel level %d: image larger than 2^31 elements", l);
     if (vox_in_place(m, &levels_out[l])) continue;
-    float* dst = (float*)((char*)pack + off);
-    hipError_t e = launch_transpose_vox(m, B, dst, (hipStream_t)stream);
+    const bool f16 = level_as_f16(m, map_dtype);
+    void* dst = (char*)pack + off;
+    hipError_t e = launch_transpose_vox(m, B, f16, dst, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "transpose_vox launch");
     levels_out[l].data = dst;
     levels_out[l].C = m.C; levels_out[l].D = m.D; levels_out[l].H = m.H; levels_out[l].W = m.W;
+    levels_out[l].dtype = f16 ? LIST_MAP_F16 : LIST_MAP_F32; levels_out[l].reserved_ = 0;
     levels_out[l].image_stride = (int64_t)m.C * m.D * m.H * m.W;
-    off += align_up((size_t)B * m.C * m.D * m.H * m.W * sizeof(float), 256);
+    off += align_up((size_t)B * m.C * m.D * m.H * m.W * (f16 ? 2 : 4), 256);
   }
   return LIST_OK;
 }
@@ -339,6 +363,8 @@ int list_percep_pool_fwd(const ListPoolArgs* a, void* stream) {
   if (a->B <= 0 || a->N <= 0 || a->map_size < 2 || a->img_C <= 0 || a->img_C % 4)
     return fail(LIST_ERR_SHAPE, "B=%d N=%d map_size=%d img_C=%d", a->B, a->N, a->map_size, a->img_C);
   if (!aligned16(a->img_map)) return fail(LIST_ERR_SHAPE, "img_map must be 16-byte aligned");
+  if (!dtype_ok(a->img_dtype) || (a->img_dtype == LIST_MAP_F16 && a->img_C % 8))
+    return fail(LIST_ERR_ARG, "img_dtype=%d img_C=%d", a->img_dtype, a->img_C);
   if ((int64_t)a->map_size * a->map_size * a->img_C >= (int64_t)1 << 31)
     return fail(LIST_ERR_SHAPE, "image map larger than 2^31 elements");
   hipError_t e = launch_percep_pool(*a, (hipStream_t)stream);

@@ -43,6 +43,10 @@ __device__ __forceinline__ unsigned short f2h(float x) {
 __device__ __forceinline__ float h2f(unsigned short h) {
   return (float)__builtin_bit_cast(_Float16, h);
 }
+__device__ __forceinline__ void put_map(void* out, int64_t i, float v, int f16) {   // scalar fallback paths
+  if (f16) ((unsigned short*)out)[i] = f2h(v);
+  else ((float*)out)[i] = v;
+}
 __device__ __forceinline__ uint2 half4(const float4& v) {
   return make_uint2((unsigned)f2h(v.x) | ((unsigned)f2h(v.y) << 16),
                     (unsigned)f2h(v.z) | ((unsigned)f2h(v.w) << 16));
@@ -228,8 +232,8 @@ enum { EPI_RELU_SPLIT = 0, EPI_F32 = 1, EPI_RELU_DOT = 2 };
 
 // ---- launchers (defined in the .hip files) ----------------------------------------------------
 hipError_t launch_prep_img(const ListMap2D maps[LIST_N_IMG_LEVELS], int B, int map_size, int Ct,
-                           float* out, hipStream_t s);
-hipError_t launch_transpose_vox(const ListMap3D& m, int B, float* out, hipStream_t s);
+                           int f16, void* out, hipStream_t s);
+hipError_t launch_transpose_vox(const ListMap3D& m, int B, int f16, void* out, hipStream_t s);
 hipError_t launch_prep_weights(const ListMlpWeights& w, const FeatLayout& L, const PackedMlp& P,
                                char* packed, hipStream_t s);
 hipError_t launch_split(const float* x, unsigned short* hi, unsigned short* lo, int64_t n, int fmt,

@@ -17,8 +17,8 @@ namespace list {
 constexpr int kResizeCg = 32;
 constexpr int kResizeMaxMs = 320;
 
-__global__ __launch_bounds__(256) void k_prep_img(ListMap2D m, int ms, int Ct, int coff,
-                                                  float* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_prep_img(ListMap2D m, int ms, int Ct, int coff, int f16,
+                                                  void* __restrict__ out) {
   __shared__ float tile[kResizeMaxMs * (kResizeCg + 1)];
   const int b = blockIdx.x / ms;
   const int y = blockIdx.x - b * ms;
@@ -50,11 +50,11 @@ __global__ __launch_bounds__(256) void k_prep_img(ListMap2D m, int ms, int Ct, i
     tile[x * (kResizeCg + 1) + cl] = top * wy0 + bot * wy1;
   }
   __syncthreads();
-  float* orow = out + ((int64_t)(b * ms + y) * ms) * Ct + coff + c0;
+  const int64_t orow = ((int64_t)(b * ms + y) * ms) * Ct + coff + c0;
   for (int idx = threadIdx.x; idx < ms * kResizeCg; idx += 256) {
     const int x = idx / kResizeCg;
     const int cl = idx - x * kResizeCg;
-    if (cl < nc) orow[(int64_t)x * Ct + cl] = tile[x * (kResizeCg + 1) + cl];
+    if (cl < nc) put_map(out, orow + (int64_t)x * Ct + cl, tile[x * (kResizeCg + 1) + cl], f16);
   }
 }
 
@@ -63,9 +63,9 @@ __global__ __launch_bounds__(256) void k_prep_img(ListMap2D m, int ms, int Ct, i
 // coalesced along x), then every thread produces 4 channels of one output pixel from four
 // ds_read_b128 and stores 16 B; consecutive lanes = consecutive channel quads = contiguous stores.
 // Arithmetic and rounding are identical to k_prep_img.
-template <int G>
+template <int G, int F16>
 __global__ __launch_bounds__(256) void k_prep_img_rows(ListMap2D m, int ms, int Ct, int coff,
-                                                       float* __restrict__ out) {
+                                                       void* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float rows[];     // [2][W][G + 4]
   constexpr int S = G + 4;
   const int b = blockIdx.x / ms;
@@ -102,52 +102,68 @@ __global__ __launch_bounds__(256) void k_prep_img_rows(ListMap2D m, int ms, int 
     }
   }
   __syncthreads();
-  constexpr int Q = G / 4;
-  float* orow = out + ((int64_t)(b * ms + y) * ms) * Ct + coff + c0;
+  constexpr int VO = F16 ? 8 : 4;          // channels per thread: one 16-B store either way
+  constexpr int Q = G / VO;
+  const int64_t orow = ((int64_t)(b * ms + y) * ms) * Ct + coff + c0;
   for (int idx = threadIdx.x; idx < ms * Q; idx += 256) {
     const int x = idx / Q, q = idx - x * Q;
     const float fx = sx * (float)x;
     const int x0 = min((int)fx, m.W - 1);
     const int x1 = x0 + (x0 < m.W - 1 ? 1 : 0);
     const float wx1 = fx - (float)x0, wx0 = 1.f - wx1;
-    const float4 v00 = *(const float4*)(rows + x0 * S + q * 4);
-    const float4 v01 = *(const float4*)(rows + x1 * S + q * 4);
-    const float4 v10 = *(const float4*)(rows + (m.W + x0) * S + q * 4);
-    const float4 v11 = *(const float4*)(rows + (m.W + x1) * S + q * 4);
-    float4 o;
-    o.x = (v00.x * wx0 + v01.x * wx1) * wy0 + (v10.x * wx0 + v11.x * wx1) * wy1;
-    o.y = (v00.y * wx0 + v01.y * wx1) * wy0 + (v10.y * wx0 + v11.y * wx1) * wy1;
-    o.z = (v00.z * wx0 + v01.z * wx1) * wy0 + (v10.z * wx0 + v11.z * wx1) * wy1;
-    o.w = (v00.w * wx0 + v01.w * wx1) * wy0 + (v10.w * wx0 + v11.w * wx1) * wy1;
-    *(float4*)(orow + (int64_t)x * Ct + q * 4) = o;
+    float o[VO];
+#pragma unroll
+    for (int h = 0; h < VO / 4; ++h) {
+      const int c = q * VO + 4 * h;
+      const float4 v00 = *(const float4*)(rows + x0 * S + c);
+      const float4 v01 = *(const float4*)(rows + x1 * S + c);
+      const float4 v10 = *(const float4*)(rows + (m.W + x0) * S + c);
+      const float4 v11 = *(const float4*)(rows + (m.W + x1) * S + c);
+      o[4 * h + 0] = (v00.x * wx0 + v01.x * wx1) * wy0 + (v10.x * wx0 + v11.x * wx1) * wy1;
+      o[4 * h + 1] = (v00.y * wx0 + v01.y * wx1) * wy0 + (v10.y * wx0 + v11.y * wx1) * wy1;
+      o[4 * h + 2] = (v00.z * wx0 + v01.z * wx1) * wy0 + (v10.z * wx0 + v11.z * wx1) * wy1;
+      o[4 * h + 3] = (v00.w * wx0 + v01.w * wx1) * wy0 + (v10.w * wx0 + v11.w * wx1) * wy1;
+    }
+    const int64_t oi = orow + (int64_t)x * Ct + q * VO;
+    if (F16) {
+      const uint2 lo = half4(make_float4(o[0], o[1], o[2], o[3]));
+      const uint2 hi = half4(make_float4(o[VO - 4], o[VO - 3], o[VO - 2], o[VO - 1]));
+      *(uint4*)((unsigned short*)out + oi) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    } else {
+      *(float4*)((float*)out + oi) = make_float4(o[0], o[1], o[2], o[3]);
+    }
   }
 }
 
 template <int G>
-static bool try_prep_img_rows(const ListMap2D& m, int B, int ms, int Ct, int coff, float* out,
+static bool try_prep_img_rows(const ListMap2D& m, int B, int ms, int Ct, int coff, int f16, void* out,
                               hipStream_t s, hipError_t* e) {
   const size_t lds = (size_t)2 * m.W * (G + 4) * sizeof(float);
-  if (m.sw != 1 || (m.C % G) != 0 || lds > 65536 || (coff % 4) != 0 || (Ct % 4) != 0) return false;
-  hipLaunchKernelGGL(k_prep_img_rows<G>, dim3(B * ms, m.C / G), dim3(256), lds, s, m, ms, Ct, coff, out);
+  const int align = f16 ? 8 : 4;
+  if (m.sw != 1 || (m.C % G) != 0 || lds > 65536 || (coff % align) != 0 || (Ct % align) != 0) return false;
+  if (f16)
+    hipLaunchKernelGGL((k_prep_img_rows<G, 1>), dim3(B * ms, m.C / G), dim3(256), lds, s, m, ms, Ct, coff, out);
+  else
+    hipLaunchKernelGGL((k_prep_img_rows<G, 0>), dim3(B * ms, m.C / G), dim3(256), lds, s, m, ms, Ct, coff, out);
   *e = hipGetLastError();
   return true;
 }
 
 hipError_t launch_prep_img(const ListMap2D maps[LIST_N_IMG_LEVELS], int B, int map_size, int Ct,
-                           float* out, hipStream_t s) {
+                           int f16, void* out, hipStream_t s) {
   int coff = 0;
   for (int i = 0; i < LIST_N_IMG_LEVELS; ++i) {
     const ListMap2D& m = maps[i];
     hipError_t fe = hipSuccess;
-    if (try_prep_img_rows<32>(m, B, map_size, Ct, coff, out, s, &fe) ||
-        try_prep_img_rows<16>(m, B, map_size, Ct, coff, out, s, &fe) ||
-        try_prep_img_rows<8>(m, B, map_size, Ct, coff, out, s, &fe)) {
+    if (try_prep_img_rows<32>(m, B, map_size, Ct, coff, f16, out, s, &fe) ||
+        try_prep_img_rows<16>(m, B, map_size, Ct, coff, f16, out, s, &fe) ||
+        try_prep_img_rows<8>(m, B, map_size, Ct, coff, f16, out, s, &fe)) {
       if (fe != hipSuccess) return fe;
       coff += m.C;
       continue;
     }
     dim3 grid(B * map_size, (m.C + kResizeCg - 1) / kResizeCg);
-    hipLaunchKernelGGL(k_prep_img, grid, dim3(256), 0, s, m, map_size, Ct, coff, out);
+    hipLaunchKernelGGL(k_prep_img, grid, dim3(256), 0, s, m, map_size, Ct, coff, f16, out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     coff += m.C;
@@ -161,8 +177,8 @@ hipError_t launch_prep_img(const ListMap2D maps[LIST_N_IMG_LEVELS], int B, int m
 // --------------------------------------------------------------------------------------------
 constexpr int kTrMaxC = 128;
 
-__global__ __launch_bounds__(256) void k_transpose_vox(ListMap3D m, int c_begin, int nc,
-                                                       float* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_transpose_vox(ListMap3D m, int c_begin, int nc, int f16,
+                                                       void* __restrict__ out) {
   __shared__ float tile[kTrMaxC * 65];
   const int nvox = m.D * m.H * m.W;
   const int b = blockIdx.y;
@@ -179,10 +195,10 @@ __global__ __launch_bounds__(256) void k_transpose_vox(ListMap3D m, int c_begin,
   }
   __syncthreads();
   const int nv = min(64, nvox - v0);
-  float* dst = out + ((int64_t)b * nvox + v0) * m.C + c_begin;
+  const int64_t dst = ((int64_t)b * nvox + v0) * m.C + c_begin;
   for (int idx = threadIdx.x; idx < nv * nc; idx += 256) {
     const int vl = idx / nc, c = idx - vl * nc;
-    dst[(int64_t)vl * m.C + c] = tile[c * 65 + vl];
+    put_map(out, dst + (int64_t)vl * m.C + c, tile[c * 65 + vl], f16);
   }
 }
 
@@ -191,10 +207,10 @@ __global__ __launch_bounds__(256) void k_transpose_vox(ListMap3D m, int c_begin,
 // stores along the channel axis (fully contiguous), LDS image [v][c] with the element index XORed by
 // ((v>>2)&7)<<2 (a bijection inside each group of 4 voxels) so that the transposing ds_write_b32
 // pattern spreads over 8 bank groups and the ds_read_b128 of 4 channels stays 16-B aligned.
-template <int C>
+template <int C, int F16>
 __global__ __launch_bounds__(256) void k_transpose_vox_tile(const float* __restrict__ src, int64_t sb,
                                                             int64_t sc, int nvox,
-                                                            float* __restrict__ out) {
+                                                            void* __restrict__ out) {
   constexpr int V = 8192 / C;          // voxels per tile
   constexpr int V4 = V / 4;
   __shared__ __attribute__((aligned(16))) float tile[8192];
@@ -217,25 +233,46 @@ __global__ __launch_bounds__(256) void k_transpose_vox_tile(const float* __restr
     tile[(a + 3 * C) ^ swz] = t.w;
   }
   __syncthreads();
-  float* dst = out + ((int64_t)b * nvox + v0) * C;
+  const int64_t dst = ((int64_t)b * nvox + v0) * C;
+  if (F16) {
+    // 8 channels (two swizzled 16-B LDS reads) -> one 16-B store of 8 halfs
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int idx = threadIdx.x + 256 * i;            // = v * (C/4) + c4
-    const int v = idx / (C / 4);
-    const int a = idx * 4;                             // v * C + 4 * c4
-    __builtin_nontemporal_store(*(const f32x4*)(tile + (a ^ (((v >> 2) & 7) << 2))), (f32x4*)(dst + a));
+    for (int i = 0; i < 4; ++i) {
+      const int idx = threadIdx.x + 256 * i;          // = v * (C/8) + c8
+      const int v = idx / (C / 8);
+      const int a = idx * 8;                           // v * C + 8 * c8
+      const int sw = ((v >> 2) & 7) << 2;
+      const float4 lo = *(const float4*)(tile + (a ^ sw));
+      const float4 hi = *(const float4*)(tile + ((a + 4) ^ sw));
+      const uint2 l = half4(lo), h = half4(hi);
+      __builtin_nontemporal_store((f32x4){__builtin_bit_cast(float, l.x), __builtin_bit_cast(float, l.y),
+                                          __builtin_bit_cast(float, h.x), __builtin_bit_cast(float, h.y)},
+                                  (f32x4*)((unsigned short*)out + dst + a));
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = threadIdx.x + 256 * i;          // = v * (C/4) + c4
+      const int v = idx / (C / 4);
+      const int a = idx * 4;                           // v * C + 4 * c4
+      __builtin_nontemporal_store(*(const f32x4*)(tile + (a ^ (((v >> 2) & 7) << 2))),
+                                  (f32x4*)((float*)out + dst + a));
+    }
   }
 }
 
 template <int C>
-static hipError_t launch_transpose_tile(const ListMap3D& m, int B, float* out, hipStream_t s) {
+static hipError_t launch_transpose_tile(const ListMap3D& m, int B, int f16, void* out, hipStream_t s) {
   const int nvox = m.D * m.H * m.W;
-  hipLaunchKernelGGL(k_transpose_vox_tile<C>, dim3(nvox / (8192 / C), B), dim3(256), 0, s, m.data, m.sb,
-                     m.sc, nvox, out);
+  const dim3 grid(nvox / (8192 / C), B);
+  if (f16)
+    hipLaunchKernelGGL((k_transpose_vox_tile<C, 1>), grid, dim3(256), 0, s, m.data, m.sb, m.sc, nvox, out);
+  else
+    hipLaunchKernelGGL((k_transpose_vox_tile<C, 0>), grid, dim3(256), 0, s, m.data, m.sb, m.sc, nvox, out);
   return hipGetLastError();
 }
 
-hipError_t launch_transpose_vox(const ListMap3D& m, int B, float* out, hipStream_t s) {
+hipError_t launch_transpose_vox(const ListMap3D& m, int B, int f16, void* out, hipStream_t s) {
   const int nvox = m.D * m.H * m.W;
   const bool spatial_contig = m.sw == 1 && m.sh == m.W && m.sd == (int64_t)m.H * m.W;
   const bool aligned = (reinterpret_cast<uintptr_t>(m.data) & 15) == 0 && (m.sb % 4) == 0 &&
@@ -243,16 +280,16 @@ hipError_t launch_transpose_vox(const ListMap3D& m, int B, float* out, hipStream
   if (spatial_contig && aligned && (m.C == 16 || m.C == 32 || m.C == 64 || m.C == 128) &&
       nvox % (8192 / m.C) == 0) {
     switch (m.C) {
-      case 16: return launch_transpose_tile<16>(m, B, out, s);
-      case 32: return launch_transpose_tile<32>(m, B, out, s);
-      case 64: return launch_transpose_tile<64>(m, B, out, s);
-      default: return launch_transpose_tile<128>(m, B, out, s);
+      case 16: return launch_transpose_tile<16>(m, B, f16, out, s);
+      case 32: return launch_transpose_tile<32>(m, B, f16, out, s);
+      case 64: return launch_transpose_tile<64>(m, B, f16, out, s);
+      default: return launch_transpose_tile<128>(m, B, f16, out, s);
     }
   }
   for (int c0 = 0; c0 < m.C; c0 += kTrMaxC) {
     const int nc = m.C - c0 < kTrMaxC ? m.C - c0 : kTrMaxC;
     dim3 grid((nvox + 63) / 64, B);
-    hipLaunchKernelGGL(k_transpose_vox, grid, dim3(256), 0, s, m, c0, nc, out);
+    hipLaunchKernelGGL(k_transpose_vox, grid, dim3(256), 0, s, m, c0, nc, f16, out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }

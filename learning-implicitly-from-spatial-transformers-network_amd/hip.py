@@ -19,6 +19,14 @@ PREC_BF16X3 = 0
 PREC_BF16 = 1
 PREC_FP16 = 2
 PRECISIONS = {"bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "fp16": PREC_FP16}
+MAP_F32, MAP_F16 = 0, 1
+MAP_DTYPES = {"f32": MAP_F32, "f16": MAP_F16}
+
+
+def map_dtype_for(precision):
+    """fp16 maps pair with the fp16 MLP (features are rounded to fp16 after interpolation anyway);
+    the fp32-grade and bf16 paths keep fp32 maps."""
+    return "f16" if precision in ("fp16", PREC_FP16) else "f32"
 
 
 class ListMap2D(C.Structure):
@@ -34,7 +42,8 @@ class ListMap3D(C.Structure):
 
 class ListVoxLevel(C.Structure):
     _fields_ = [("data", C.c_void_p), ("C", C.c_int32), ("D", C.c_int32), ("H", C.c_int32),
-                ("W", C.c_int32), ("image_stride", C.c_int64)]
+                ("W", C.c_int32), ("dtype", C.c_int32), ("reserved_", C.c_int32),
+                ("image_stride", C.c_int64)]
 
 
 class ListMlpWeights(C.Structure):
@@ -49,8 +58,8 @@ class ListQueryArgs(C.Structure):
                 ("query", C.c_void_p), ("q_sb", C.c_int64), ("q_sn", C.c_int64), ("q_sc", C.c_int64),
                 ("perm", C.c_int32 * 3), ("scale", C.c_float),
                 ("trans_mat", C.c_void_p),
-                ("img_map", C.c_void_p), ("map_size", C.c_int32), ("img_C", C.c_int32),
-                ("clamp_hi", C.c_float),
+                ("img_map", C.c_void_p), ("img_dtype", C.c_int32), ("map_size", C.c_int32),
+                ("img_C", C.c_int32), ("clamp_hi", C.c_float),
                 ("percep_feat", C.c_void_p), ("pf_sb", C.c_int64), ("pf_sc", C.c_int64),
                 ("pf_sn", C.c_int64),
                 ("vox", ListVoxLevel * N_VOX_LEVELS),
@@ -72,17 +81,17 @@ class ListPoolArgs(C.Structure):
     _fields_ = [("B", C.c_int32), ("N", C.c_int32),
                 ("pc", C.c_void_p), ("p_sb", C.c_int64), ("p_sn", C.c_int64), ("p_sc", C.c_int64),
                 ("trans_mat", C.c_void_p),
-                ("img_map", C.c_void_p), ("map_size", C.c_int32), ("img_C", C.c_int32),
-                ("clamp_hi", C.c_float),
+                ("img_map", C.c_void_p), ("img_dtype", C.c_int32), ("map_size", C.c_int32),
+                ("img_C", C.c_int32), ("clamp_hi", C.c_float),
                 ("out", C.c_void_p)]
 
 
 EXPORTS = {
-    "list_img_map_bytes": (C.c_size_t, [C.POINTER(ListMap2D), C.c_int32, C.c_int32]),
-    "list_prep_img_maps": (C.c_int, [C.POINTER(ListMap2D), C.c_int32, C.c_int32, C.c_void_p,
+    "list_img_map_bytes": (C.c_size_t, [C.POINTER(ListMap2D), C.c_int32, C.c_int32, C.c_int32]),
+    "list_prep_img_maps": (C.c_int, [C.POINTER(ListMap2D), C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                      C.c_size_t, C.c_void_p]),
-    "list_vox_pack_bytes": (C.c_size_t, [C.POINTER(ListMap3D), C.c_int32]),
-    "list_prep_vox_maps": (C.c_int, [C.POINTER(ListMap3D), C.c_int32, C.c_void_p, C.c_size_t,
+    "list_vox_pack_bytes": (C.c_size_t, [C.POINTER(ListMap3D), C.c_int32, C.c_int32]),
+    "list_prep_vox_maps": (C.c_int, [C.POINTER(ListMap3D), C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
                                      C.POINTER(ListVoxLevel), C.c_void_p]),
     "list_packed_mlp_bytes": (C.c_size_t, [C.POINTER(ListMlpWeights)]),
     "list_prep_mlp_weights": (C.c_int, [C.POINTER(ListMlpWeights), C.c_void_p, C.c_size_t,
@@ -144,10 +153,10 @@ def _f32_cuda(t, name):
 
 # ------------------------------------------------------------------------------------------------
 class PreparedImage:
-    """Channels-last resized perceptual map [B,ms,ms,Ct] (+ the sources it was built from)."""
+    """Channels-last resized perceptual map [B,ms,ms,Ct], float32 or float16."""
 
-    def __init__(self, data, map_size, channels):
-        self.data, self.map_size, self.channels = data, map_size, channels
+    def __init__(self, data, map_size, channels, dtype):
+        self.data, self.map_size, self.channels, self.dtype = data, map_size, channels, dtype
 
 
 class PreparedVoxels:
@@ -167,9 +176,10 @@ class PackedMlp:
         self.vox_C, self.img_C, self.fp16 = list(vox_C), img_C, fp16
 
 
-def prep_img_maps(img_featuremaps, map_size=137):
+def prep_img_maps(img_featuremaps, map_size=137, dtype="f32"):
     """F.interpolate x5 (+ layout) of the reference, network/modules.py:26-35."""
     lib = load()
+    md = MAP_DTYPES[dtype]
     if len(img_featuremaps) != N_IMG_LEVELS:
         raise RuntimeError(f"expected {N_IMG_LEVELS} image feature maps, got {len(img_featuremaps)}")
     maps = (ListMap2D * N_IMG_LEVELS)()
@@ -181,16 +191,18 @@ def prep_img_maps(img_featuremaps, map_size=137):
             raise RuntimeError(f"img_featuremaps[{i}] must be [B,C,H,W]")
         maps[i] = ListMap2D(t.data_ptr(), t.shape[1], t.shape[2], t.shape[3], *t.stride())
         Ct += t.shape[1]
-    out = torch.empty((B, map_size, map_size, Ct), dtype=torch.float32, device=img_featuremaps[0].device)
+    out = torch.empty((B, map_size, map_size, Ct), dtype=torch.float16 if md == MAP_F16 else torch.float32,
+                      device=img_featuremaps[0].device)
     with torch.cuda.device(out.device):
-        _check(lib.list_prep_img_maps(maps, B, map_size, out.data_ptr(), out.numel() * 4, _stream()),
-               "list_prep_img_maps")
-    return PreparedImage(out, map_size, Ct)
+        _check(lib.list_prep_img_maps(maps, B, map_size, md, out.data_ptr(),
+                                      out.numel() * out.element_size(), _stream()), "list_prep_img_maps")
+    return PreparedImage(out, map_size, Ct, md)
 
 
-def prep_vox_maps(vox_feat):
+def prep_vox_maps(vox_feat, dtype="f32"):
     """Layout hand-off for the 3-D grid_sample of network/modules.py:263-265."""
     lib = load()
+    md = MAP_DTYPES[dtype]
     if len(vox_feat) != N_VOX_LEVELS:
         raise RuntimeError(f"expected {N_VOX_LEVELS} voxel feature maps, got {len(vox_feat)}")
     maps = (ListMap3D * N_VOX_LEVELS)()
@@ -200,12 +212,12 @@ def prep_vox_maps(vox_feat):
         if t.dim() != 5 or t.shape[0] != B:
             raise RuntimeError(f"vox_feat[{i}] must be [B,C,D,H,W]")
         maps[i] = ListMap3D(t.data_ptr(), t.shape[1], t.shape[2], t.shape[3], t.shape[4], *t.stride())
-    need = lib.list_vox_pack_bytes(maps, B)
+    need = lib.list_vox_pack_bytes(maps, B, md)
     dev = vox_feat[0].device
     pack = torch.empty((max(need, 16) // 4,), dtype=torch.float32, device=dev)
     levels = (ListVoxLevel * N_VOX_LEVELS)()
     with torch.cuda.device(dev):
-        _check(lib.list_prep_vox_maps(maps, B, pack.data_ptr(), pack.numel() * 4, levels, _stream()),
+        _check(lib.list_prep_vox_maps(maps, B, md, pack.data_ptr(), pack.numel() * 4, levels, _stream()),
                "list_prep_vox_maps")
     return PreparedVoxels(levels, (pack, list(vox_feat)))
 
@@ -293,6 +305,7 @@ def _fill_query_args(query, perm, scale, vox, packed, precision, trans_mat=None,
         tm = _f32_cuda(trans_mat, "trans_mat").reshape(B, 4, 3).contiguous()
         a.trans_mat = tm.data_ptr()
         a.img_map = img.data.data_ptr()
+        a.img_dtype = img.dtype
         a.map_size, a.img_C = img.map_size, img.channels
         a.clamp_hi = float(clamp_hi)
         keep += [tm, img]
@@ -357,6 +370,7 @@ def percep_pool(pc, trans_mat, img, clamp_hi=136.0):
     a.p_sb, a.p_sn, a.p_sc = pc.stride()
     a.trans_mat = tm.data_ptr()
     a.img_map, a.map_size, a.img_C = img.data.data_ptr(), img.map_size, img.channels
+    a.img_dtype = img.dtype
     a.clamp_hi = float(clamp_hi)
     a.out = out.data_ptr()
     with torch.cuda.device(pc.device):

@@ -109,14 +109,15 @@ def sdf_query(query, trans_mat, img_maps, vox_maps, mlp_params, *, perm=(2, 1, 0
     query = _f32(query)
     vox_maps = [_f32(v) for v in vox_maps]
     mlp = [mlp_params[k] for k in MLP_KEYS]
+    md = hip.map_dtype_for(precision)
     if percep_feat is None:
         img_maps = [_f32(m) for m in img_maps]
-        img = caches.setdefault("img", _Cache()).get(
-            img_maps, lambda: hip.prep_img_maps([m.detach() for m in img_maps], map_size))
+        img = caches.setdefault("img:" + md, _Cache()).get(
+            img_maps, lambda: hip.prep_img_maps([m.detach() for m in img_maps], map_size, md))
     else:
         img_maps, img = [], None
-    vox = caches.setdefault("vox", _Cache()).get(
-        vox_maps, lambda: hip.prep_vox_maps([v.detach() for v in vox_maps]))
+    vox = caches.setdefault("vox:" + md, _Cache()).get(
+        vox_maps, lambda: hip.prep_vox_maps([v.detach() for v in vox_maps], md))
     img_C = img.channels if img is not None else percep_feat.shape[1]
     packed = caches.setdefault("mlp:" + str(precision), _Cache()).get(
         mlp, lambda: hip.prep_mlp_weights({k: t.detach() for k, t in zip(MLP_KEYS, mlp)},

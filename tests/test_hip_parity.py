@@ -35,9 +35,10 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
 
 
-def prepare(hip, c, precision="bf16x3"):
-    img = hip.prep_img_maps([dev(m) for m in c["img_maps"]])
-    vox = hip.prep_vox_maps([dev(m) for m in c["vox_maps"]])
+def prepare(hip, c, precision="bf16x3", map_dtype=None):
+    md = map_dtype or hip.map_dtype_for(precision)        # fp16 MLP pairs with fp16 maps
+    img = hip.prep_img_maps([dev(m) for m in c["img_maps"]], dtype=md)
+    vox = hip.prep_vox_maps([dev(m) for m in c["vox_maps"]], dtype=md)
     packed = hip.prep_mlp_weights({k: dev(v) for k, v in c["weights"].items()},
                                   vox.channels, img.channels, precision)
     return img, vox, packed
@@ -106,6 +107,27 @@ def test_prep_vox_is_exact_transpose(hip):
         got = pack[off:off + n].reshape(B, D, H, W, Cc)
         np.testing.assert_array_equal(got, np.transpose(m, (0, 2, 3, 4, 1)))
         off += (n * 4 + 255) // 256 * 256 // 4
+
+
+def test_prep_maps_fp16_are_rne_of_the_fp32_result(hip):
+    c = cases.build_case("small")
+    vox = hip.prep_vox_maps([dev(m) for m in c["vox_maps"]], dtype="f16")
+    pack = vox._keep[0].view(torch.float16).cpu().numpy()
+    off = 0
+    for l, m in enumerate(c["vox_maps"]):
+        B, Cc, D, H, W = m.shape
+        if Cc == 1:
+            assert vox.levels[l].dtype == hip.MAP_F32          # scalar level stays fp32, in place
+            continue
+        assert vox.levels[l].dtype == hip.MAP_F16
+        n = B * Cc * D * H * W
+        got = pack[off:off + n].reshape(B, D, H, W, Cc)
+        np.testing.assert_array_equal(got, np.transpose(m, (0, 2, 3, 4, 1)).astype(np.float16))
+        off += (n * 2 + 255) // 256 * 256 // 2
+    img32 = hip.prep_img_maps([dev(m) for m in c["img_maps"]], dtype="f32").data.cpu().numpy()
+    img16 = hip.prep_img_maps([dev(m) for m in c["img_maps"]], dtype="f16").data.cpu().numpy()
+    assert img16.dtype == np.float16
+    np.testing.assert_array_equal(img16, img32.astype(np.float16))
 
 
 def test_prep_vox_accepts_channels_last_in_place(hip):
@@ -178,12 +200,17 @@ def test_fused_sdf_matches_reference(hip, golden_dir, name):
     err1 = np.abs(sdf1 - g["sdf"]).max()
     print(f"{name}: bf16 max-abs err {err1:.3e}")
     assert err1 < TOL_BF16
-    _, _, packed16 = prepare(hip, c, "fp16")
-    sdf2 = hip.sdf_query(dev(c["query"]), dev(c["trans_mat"]), img, vox, packed16,
+    img16, vox16, packed16 = prepare(hip, c, "fp16")                   # fp16 maps + fp16 MLP operands
+    sdf2 = hip.sdf_query(dev(c["query"]), dev(c["trans_mat"]), img16, vox16, packed16,
                          precision="fp16").cpu().numpy()
     err2 = np.abs(sdf2 - g["sdf"]).max()
-    print(f"{name}: fp16 max-abs err {err2:.3e}")
+    print(f"{name}: fp16 (fp16 maps) max-abs err {err2:.3e}")
     assert err2 < TOL_FP16
+    sdf3 = hip.sdf_query(dev(c["query"]), dev(c["trans_mat"]), img, vox, packed16,
+                         precision="fp16").cpu().numpy()                # fp32 maps + fp16 MLP operands
+    err3 = np.abs(sdf3 - g["sdf"]).max()
+    print(f"{name}: fp16 (fp32 maps) max-abs err {err3:.3e}")
+    assert err3 < TOL_FP16
     with pytest.raises(RuntimeError, match="different precision"):
         hip.sdf_query(dev(c["query"]), dev(c["trans_mat"]), img, vox, packed, precision="fp16")
 
@@ -288,8 +315,8 @@ def test_full_size_properties(hip, full_case):
     err = np.abs(sdf.cpu().numpy()[:, idx] - ref).max()
     print(f"full-size subset max-abs err {err:.3e}")
     assert err < TOL_X3
-    _, _, packed16 = prepare(hip, c, "fp16")
-    sdf16 = hip.sdf_query(q, T, img, vox, packed16, precision="fp16")
+    img16, vox16, packed16 = prepare(hip, c, "fp16")
+    sdf16 = hip.sdf_query(q, T, img16, vox16, packed16, precision="fp16")
     err16 = np.abs(sdf16.cpu().numpy()[:, idx] - ref).max()
     print(f"full-size subset fp16 max-abs err {err16:.3e}; fp16 vs bf16x3 over all points "
           f"{float((sdf16 - sdf).abs().max()):.3e}")
