@@ -58,73 +58,82 @@ __global__ __launch_bounds__(256) void k_prep_img(ListMap2D m, int ms, int Ct, i
   }
 }
 
-// Fast path (W-contiguous source rows, C % G == 0): a workgroup owns one output row y of G channels.
-// It stages the two source rows (y0, y1) of those channels in LDS transposed to [x][c] (global reads
-// coalesced along x), then every thread produces 4 channels of one output pixel from four
-// ds_read_b128 and stores 16 B; consecutive lanes = consecutive channel quads = contiguous stores.
-// Arithmetic and rounding are identical to k_prep_img.
-template <int G, int F16>
-__global__ __launch_bounds__(256) void k_prep_img_rows(ListMap2D m, int ms, int Ct, int coff,
-                                                       void* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float rows[];     // [2][W][G + 4]
-  constexpr int S = G + 4;
-  const int b = blockIdx.x / ms;
-  const int y = blockIdx.x - b * ms;
+// Fast path (W-contiguous source rows, C % 32 == 0): a workgroup owns a tile of RY output rows x one
+// x-range x 32 channels.  It stages the source rows the tile needs in LDS transposed to [row][x][c]
+// (global reads coalesced along x), then every thread produces 4 (fp32) or 8 (fp16) channels of one
+// output pixel from ds_read_b128s and issues one 16-B store; consecutive lanes = consecutive channel
+// groups = contiguous 128-B (64-B) runs.  RY > 1 for the up-sampled levels (14, 28, 56 px -> 137:
+// consecutive output rows share their source rows), an x split for the widest level keeps the tile in
+// 32 KB of LDS.  Arithmetic and rounding are identical to k_prep_img.
+constexpr int kTileG = 32;
+
+template <int F16>
+__global__ __launch_bounds__(256) void k_prep_img_tile(ListMap2D m, int ms, int Ct, int coff,
+                                                       void* __restrict__ out, int RY, int XS, int WT) {
+  extern __shared__ __attribute__((aligned(16))) float rows[];     // [nr][WT][G + 4]
+  constexpr int G = kTileG, S = G + 4;
+  const int nyb = (ms + RY - 1) / RY, nxo = (ms + XS - 1) / XS;
+  int bid = blockIdx.x;
+  const int xs = bid % XS; bid /= XS;
+  const int yb = bid % nyb;
+  const int b = bid / nyb;
   const int c0 = blockIdx.y * G;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
   const float sy = ms > 1 ? (float)(m.H - 1) / (float)(ms - 1) : 0.f;
   const float sx = ms > 1 ? (float)(m.W - 1) / (float)(ms - 1) : 0.f;
-  const float fy = sy * (float)y;
-  const int y0 = min((int)fy, m.H - 1);
-  const int y1 = y0 + (y0 < m.H - 1 ? 1 : 0);
-  const float wy1 = fy - (float)y0, wy0 = 1.f - wy1;
-  const float* base = m.data + (int64_t)b * m.sb + (int64_t)c0 * m.sc;
-  const bool vec = (m.W % 4) == 0 && (m.sh % 4) == 0 && (m.sc % 4) == 0 && (m.sb % 4) == 0 &&
-                   (reinterpret_cast<uintptr_t>(m.data) & 15) == 0;
+  const int y_first = yb * RY, y_last = min(y_first + RY, ms) - 1;
+  const int x_first = xs * nxo, x_last = min(x_first + nxo, ms) - 1;
+  if (x_first > x_last) return;
+  const int ys0 = min((int)(sy * (float)y_first), m.H - 1);
+  const int ys1 = min((int)(sy * (float)y_last) + 1, m.H - 1);
+  const int xs0 = min((int)(sx * (float)x_first), m.W - 1);
+  const int xs1 = min((int)(sx * (float)x_last) + 1, m.W - 1);
+  const int nr = ys1 - ys0 + 1, wt = xs1 - xs0 + 1;
+
+  const float* base = m.data + (int64_t)b * m.sb + (int64_t)c0 * m.sc + xs0;
+  for (int r = 0; r < nr; ++r) {
+    const float* srow = base + (int64_t)(ys0 + r) * m.sh;
+    float* drow = rows + r * WT * S;
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const float* srow = base + (int64_t)(r ? y1 : y0) * m.sh;
-    float* drow = rows + r * m.W * S;
-    if (vec) {
-#pragma unroll
-      for (int ci = 0; ci < G / 4; ++ci) {
-        const int c = wave + 4 * ci;
-        for (int x4 = lane; x4 < m.W / 4; x4 += 64) {
-          const float4 t = *(const float4*)(srow + (int64_t)c * m.sc + 4 * x4);
-          float* d = drow + (4 * x4) * S + c;
-          d[0] = t.x; d[S] = t.y; d[2 * S] = t.z; d[3 * S] = t.w;
-        }
-      }
-    } else {
-      for (int c = wave; c < G; c += 4)
-        for (int x = lane; x < m.W; x += 64) drow[x * S + c] = srow[(int64_t)c * m.sc + x];
+    for (int ci = 0; ci < G / 4; ++ci) {
+      const int c = wave + 4 * ci;
+      for (int x = lane; x < wt; x += 64) drow[x * S + c] = srow[(int64_t)c * m.sc + x];
     }
   }
   __syncthreads();
   constexpr int VO = F16 ? 8 : 4;          // channels per thread: one 16-B store either way
   constexpr int Q = G / VO;
-  const int64_t orow = ((int64_t)(b * ms + y) * ms) * Ct + coff + c0;
-  for (int idx = threadIdx.x; idx < ms * Q; idx += 256) {
-    const int x = idx / Q, q = idx - x * Q;
+  const int nx = x_last - x_first + 1, ny = y_last - y_first + 1;
+  for (int idx = threadIdx.x; idx < ny * nx * Q; idx += 256) {
+    const int q = idx % Q;
+    const int t = idx / Q;
+    const int xi = t % nx, yi = t / nx;
+    const int x = x_first + xi, y = y_first + yi;
+    const float fy = sy * (float)y;
+    const int y0 = min((int)fy, m.H - 1);
+    const int y1 = y0 + (y0 < m.H - 1 ? 1 : 0);
+    const float wy1 = fy - (float)y0, wy0 = 1.f - wy1;
     const float fx = sx * (float)x;
     const int x0 = min((int)fx, m.W - 1);
     const int x1 = x0 + (x0 < m.W - 1 ? 1 : 0);
     const float wx1 = fx - (float)x0, wx0 = 1.f - wx1;
+    const float* r0 = rows + (y0 - ys0) * WT * S;
+    const float* r1 = rows + (y1 - ys0) * WT * S;
     float o[VO];
 #pragma unroll
     for (int h = 0; h < VO / 4; ++h) {
       const int c = q * VO + 4 * h;
-      const float4 v00 = *(const float4*)(rows + x0 * S + c);
-      const float4 v01 = *(const float4*)(rows + x1 * S + c);
-      const float4 v10 = *(const float4*)(rows + (m.W + x0) * S + c);
-      const float4 v11 = *(const float4*)(rows + (m.W + x1) * S + c);
+      const float4 v00 = *(const float4*)(r0 + (x0 - xs0) * S + c);
+      const float4 v01 = *(const float4*)(r0 + (x1 - xs0) * S + c);
+      const float4 v10 = *(const float4*)(r1 + (x0 - xs0) * S + c);
+      const float4 v11 = *(const float4*)(r1 + (x1 - xs0) * S + c);
       o[4 * h + 0] = (v00.x * wx0 + v01.x * wx1) * wy0 + (v10.x * wx0 + v11.x * wx1) * wy1;
       o[4 * h + 1] = (v00.y * wx0 + v01.y * wx1) * wy0 + (v10.y * wx0 + v11.y * wx1) * wy1;
       o[4 * h + 2] = (v00.z * wx0 + v01.z * wx1) * wy0 + (v10.z * wx0 + v11.z * wx1) * wy1;
       o[4 * h + 3] = (v00.w * wx0 + v01.w * wx1) * wy0 + (v10.w * wx0 + v11.w * wx1) * wy1;
     }
-    const int64_t oi = orow + (int64_t)x * Ct + q * VO;
+    const int64_t oi = ((int64_t)(b * ms + y) * ms + x) * Ct + coff + c0 + q * VO;
     if (F16) {
       const uint2 lo = half4(make_float4(o[0], o[1], o[2], o[3]));
       const uint2 hi = half4(make_float4(o[VO - 4], o[VO - 3], o[VO - 2], o[VO - 1]));
@@ -135,16 +144,31 @@ __global__ __launch_bounds__(256) void k_prep_img_rows(ListMap2D m, int ms, int 
   }
 }
 
-template <int G>
-static bool try_prep_img_rows(const ListMap2D& m, int B, int ms, int Ct, int coff, int f16, void* out,
+static bool try_prep_img_tile(const ListMap2D& m, int B, int ms, int Ct, int coff, int f16, void* out,
                               hipStream_t s, hipError_t* e) {
-  const size_t lds = (size_t)2 * m.W * (G + 4) * sizeof(float);
   const int align = f16 ? 8 : 4;
-  if (m.sw != 1 || (m.C % G) != 0 || lds > 65536 || (coff % align) != 0 || (Ct % align) != 0) return false;
+  if (m.sw != 1 || (m.C % kTileG) != 0 || (coff % align) != 0 || (Ct % align) != 0 || ms < 2) return false;
+  const float sy = (float)(m.H - 1) / (float)(ms - 1), sx = (float)(m.W - 1) / (float)(ms - 1);
+  // rows per tile: as many as keep the staged source rows within ~32 KB, at most 8
+  int best_ry = 0, best_xs = 1, best_nr = 0, best_wt = 0;
+  for (int xs = 1; xs <= 4 && !best_ry; ++xs) {
+    const int nxo = (ms + xs - 1) / xs;
+    int wt = (int)(sx * (float)nxo) + 3;
+    if (wt > m.W) wt = m.W;
+    for (int ry = 8; ry >= 1; --ry) {
+      int nr = (int)(sy * (float)(ry - 1)) + 3;
+      if (nr > m.H) nr = m.H;
+      if ((size_t)nr * wt * (kTileG + 4) * sizeof(float) <= 32768) { best_ry = ry; best_xs = xs; best_nr = nr; best_wt = wt; break; }
+    }
+  }
+  if (!best_ry) return false;
+  const size_t lds = (size_t)best_nr * best_wt * (kTileG + 4) * sizeof(float);
+  const int nyb = (ms + best_ry - 1) / best_ry;
+  const dim3 grid((unsigned)(B * nyb * best_xs), m.C / kTileG);
   if (f16)
-    hipLaunchKernelGGL((k_prep_img_rows<G, 1>), dim3(B * ms, m.C / G), dim3(256), lds, s, m, ms, Ct, coff, out);
+    hipLaunchKernelGGL(k_prep_img_tile<1>, grid, dim3(256), lds, s, m, ms, Ct, coff, out, best_ry, best_xs, best_wt);
   else
-    hipLaunchKernelGGL((k_prep_img_rows<G, 0>), dim3(B * ms, m.C / G), dim3(256), lds, s, m, ms, Ct, coff, out);
+    hipLaunchKernelGGL(k_prep_img_tile<0>, grid, dim3(256), lds, s, m, ms, Ct, coff, out, best_ry, best_xs, best_wt);
   *e = hipGetLastError();
   return true;
 }
@@ -155,9 +179,7 @@ hipError_t launch_prep_img(const ListMap2D maps[LIST_N_IMG_LEVELS], int B, int m
   for (int i = 0; i < LIST_N_IMG_LEVELS; ++i) {
     const ListMap2D& m = maps[i];
     hipError_t fe = hipSuccess;
-    if (try_prep_img_rows<32>(m, B, map_size, Ct, coff, f16, out, s, &fe) ||
-        try_prep_img_rows<16>(m, B, map_size, Ct, coff, f16, out, s, &fe) ||
-        try_prep_img_rows<8>(m, B, map_size, Ct, coff, f16, out, s, &fe)) {
+    if (try_prep_img_tile(m, B, map_size, Ct, coff, f16, out, s, &fe)) {
       if (fe != hipSuccess) return fe;
       coff += m.C;
       continue;
