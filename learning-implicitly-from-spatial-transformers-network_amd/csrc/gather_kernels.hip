@@ -627,10 +627,17 @@ __global__ __launch_bounds__(256) void k_gather_tail(GatherParams g, TailLevels 
   put<FMT>(g, ro + xyz_off + 0, p.valid ? p.x : 0.f);     // p_features, modules.py:257
   put<FMT>(g, ro + xyz_off + 1, p.valid ? p.y : 0.f);
   put<FMT>(g, ro + xyz_off + 2, p.valid ? p.z : 0.f);
-  for (int k = F; k < g.Kp; ++k) {
-    g.x_hi[ro + k] = 0;
-    if (FMT == FMT_BF16_SPLIT) g.x_lo[ro + k] = 0;
-  }
+  // zero padding up to Kp (a multiple of 64, rows are 128-B aligned): widen the stores as the
+  // alignment allows -- 6 stores instead of 38 for F = 3610 (uniform control flow: F, Kp are uniform)
+  auto zero_pad = [&](unsigned short* __restrict__ x) {
+    int k = F;
+    if ((k & 1) && k < g.Kp) { x[ro + k] = 0; k += 1; }
+    if ((k & 2) && k + 2 <= g.Kp) { *(unsigned*)(x + ro + k) = 0u; k += 2; }
+    if ((k & 4) && k + 4 <= g.Kp) { *(uint2*)(x + ro + k) = make_uint2(0u, 0u); k += 4; }
+    for (; k + 8 <= g.Kp; k += 8) *(uint4*)(x + ro + k) = make_uint4(0u, 0u, 0u, 0u);
+  };
+  zero_pad(g.x_hi);
+  if (FMT == FMT_BF16_SPLIT) zero_pad(g.x_lo);
 }
 
 // ---- launch ----------------------------------------------------------------------------------------

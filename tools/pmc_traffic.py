@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Per-kernel HBM traffic from rocprofv3 PMC passes -> profiles/pmc_traffic.json (read by bench.py).
+
+    python tools/pmc_traffic.py <fetch_dir> <write_dir> <precision> [out.json]
+
+Correction (MI355X_MICROARCH.md, HBM section): on gfx950 FETCH_SIZE reports exactly half of the bytes
+of a wide (16 B/lane) coalesced read -> doubled; WRITE_SIZE is exact for 16 B/lane streaming stores.
+Both counters are in KB.  Kernels whose accesses are narrower (the 2-B epilogue stores of k_gemm_nt,
+the 8-B feature stores of the gathers) are outside the calibrated range: their numbers are kept but
+flagged "uncalibrated_writes".
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+csv.field_size_limit(1 << 30)
+
+
+def kernel_key(name, grid, seq):
+    m = re.search(r"list::(k_[a-z_0-9]+)(<[^>]*>)?", name)
+    if not m:
+        return None
+    k, t = m.group(1), (m.group(2) or "")
+    if k == "k_gemm_nt":
+        epi = t.strip("<>").split(",")[1].strip()
+        if epi == "2":
+            return "fc_2_out"
+        return "fc_0" if grid >= 600000 else "fc_1"
+    if k in ("k_gather_vox", "k_gather_vox_near"):
+        c = int(t.strip("<>").split(",")[0])
+        lvl = {16: "l1", 32: "l2", 64: "l3"}.get(c)
+        if lvl is None:                       # two 128-channel levels per step: l4 then l5
+            lvl = "l4" if seq[(k, c)] % 2 == 0 else "l5"
+            seq[(k, c)] += 1
+        return "gather_vox_" + lvl
+    return {"k_gather_img": "gather_img", "k_gather_tail": "gather_tail",
+            "k_transpose_vox_tile": "prep_vox_ndhwc", "k_transpose_vox": "prep_vox_ndhwc",
+            "k_prep_img_tile": "prep_img_resize_nhwc", "k_prep_img": "prep_img_resize_nhwc",
+            "k_sort_hist": "sort_points", "k_sort_scan": "sort_points", "k_sort_scatter": "sort_points"}.get(k)
+
+
+def collect(d, counter):
+    per = defaultdict(list)
+    seq = defaultdict(int)
+    for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+        rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+        for r in rows:
+            key = kernel_key(r["Kernel_Name"], int(r.get("Grid_Size", 0) or 0), seq)
+            if key:
+                per[key].append(float(r["Counter_Value"]))
+    return per
+
+
+def main():
+    fetch_dir, write_dir, precision = sys.argv[1:4]
+    out = sys.argv[4] if len(sys.argv) > 4 else "profiles/pmc_traffic.json"
+    fetch, write = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
+    groups = {"prep_vox_ndhwc": 5, "prep_img_resize_nhwc": 5, "sort_points": 6}   # launches per step
+    res = {}
+    for k in sorted(set(fetch) | set(write)):
+        n = groups.get(k, 1)
+        f_kb = sum(fetch.get(k, [])) / max(len(fetch.get(k, [])), 1) * n
+        w_kb = sum(write.get(k, [])) / max(len(write.get(k, [])), 1) * n
+        res[k] = {"hbm_bytes": 2 * f_kb * 1024 + w_kb * 1024, "fetch_size_kb_raw": f_kb,
+                  "write_size_kb_raw": w_kb, "fetch_correction": 2.0,
+                  "uncalibrated_writes": k.startswith("fc_") or k.startswith("gather")}
+    data = json.load(open(out)) if os.path.exists(out) else {}
+    data[precision] = res
+    json.dump(data, open(out, "w"), indent=1, sort_keys=True)
+    for k, v in res.items():
+        print(f"{k:24s} hbm_bytes/launch(group) = {v['hbm_bytes']/1e6:10.1f} MB  (FETCH {v['fetch_size_kb_raw']/1e3:9.1f} MB raw, "
+              f"WRITE {v['write_size_kb_raw']/1e3:9.1f} MB)")
+
+
+if __name__ == "__main__":
+    main()
