@@ -35,6 +35,7 @@ WORKLOADS = {
     # name: (B per GPU, N, img_res, vox_res, map_size, clamp_hi)
     "list_im2sdf_b8_n20k_224": (8, 20000, 224, 128, 137, 136.0),            # BASELINE configs[1]
     "list_im2sdf_b8_n50k_512": (8, 50000, 512, 128, 274, 273.0),            # BASELINE configs[4]
+    "list_grid256_b1": (1, 256 ** 3, 224, 128, 137, 136.0),                 # BASELINE configs[3]
 }
 
 
@@ -77,7 +78,12 @@ def make_inputs(workload, rank, device):
     vshapes = synth.vox_map_shapes(B, vox_res)
     vox_maps = [torch.rand(vshapes[0], generator=g, device=device)]
     vox_maps += [torch.randn(s, generator=g, device=device) for s in vshapes[1:]]
-    query = torch.rand((B, N, 3), generator=g, device=device) - 0.5
+    if workload.startswith("list_grid"):      # inference: the regular query grid of executors.py:191-197
+        from list_amd import utils
+        res = round(N ** (1 / 3))
+        query = utils.grid_points_on_device(-0.5, 0.5, res, device).unsqueeze(0)
+    else:
+        query = torch.rand((B, N, 3), generator=g, device=device) - 0.5
     trans = torch.from_numpy(synth.make_trans_mat(333 + rank, B)).to(device)
     if map_size != 137:                    # keep projections inside the larger map
         trans = trans * (map_size - 1) / 136.0
@@ -102,8 +108,9 @@ def kernel_table(B, N, img_res, vox_res, map_size, x_bytes_per_feature, map_byte
     img_elems_in = sum(int(np.prod(s)) for s in synth.img_map_shapes(B, img_res))
     img_elems_out = B * map_size * map_size * 1024
     t = {
-        "prep_img_resize_nhwc": ("hbm", 4 * (img_elems_in + img_elems_out)),
-        "prep_vox_ndhwc": ("hbm", 8 * sum(vox_elems[1:])),
+        # layout kernels: bytes actually moved (fp32 source read once + prepared map written once)
+        "prep_img_resize_nhwc": ("hbm", 4 * img_elems_in + map_bytes * img_elems_out),
+        "prep_vox_ndhwc": ("hbm", (4 + map_bytes) * sum(vox_elems[1:])),
         "gather_img": ("hbm", P * (4 * 1024 * 4 + 1024 * x_bytes_per_feature + 12)),
         "gather_tail": ("hbm", P * (7 * 8 * 4 + 48 * x_bytes_per_feature)),
         "fc_0": ("mfma", P * 2 * 3610 * 512),
@@ -138,7 +145,7 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
         packed = hip.prep_mlp_weights(inp["weights"], vox.channels, img.channels, precision)
         if pre: ev.record(pre[3])
         hip.sdf_query(inp["query"], inp["trans_mat"], img, vox, packed, precision=precision,
-                      out=sdf, stage_events=arr)
+                      out=sdf, stage_events=arr, clamp_hi=inp["clamp_hi"])
         if world > 1:
             gather_fn(sdf, out=gathered)
         return sdf
@@ -267,7 +274,7 @@ def main():
     value = world * P * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
     xb = 2 if headline != "bf16x3" else 4
-    table = kernel_table(B, N, img_res, vox_res, map_size, xb)
+    table = kernel_table(B, N, img_res, vox_res, map_size, xb, 2 if headline == "fp16" else 4)
     roof = roofline_of(kernel_ms, table, headline)
     if alt is not None:
         alt["roofline"] = roofline_of(alt["kernel_ms"], kernel_table(B, N, img_res, vox_res, map_size, 4),

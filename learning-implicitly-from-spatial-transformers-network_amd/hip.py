@@ -325,12 +325,13 @@ def _fill_query_args(query, perm, scale, vox, packed, precision, trans_mat=None,
 
 
 def sdf_query(query, trans_mat, img, vox, packed, perm=(2, 1, 0), scale=2.0, precision="bf16x3",
-              percep_feat=None, out=None, stage_events=None, sort_points=True):
+              percep_feat=None, out=None, stage_events=None, sort_points=True, clamp_hi=136.0):
     """The fused hot path, network/models.py:91-97 -> sdf [B,N] (float32).
 
     stage_events: optional ctypes array (c_void_p * N_STAGES) of hipEvent_t handles."""
     lib = load()
-    a, keep = _fill_query_args(query, perm, scale, vox, packed, precision, trans_mat, img, percep_feat)
+    a, keep = _fill_query_args(query, perm, scale, vox, packed, precision, trans_mat, img, percep_feat,
+                               clamp_hi)
     a.no_sort = 0 if sort_points else 1
     if stage_events is not None:
         a.stage_events = C.cast(stage_events, C.POINTER(C.c_void_p))

@@ -54,9 +54,10 @@ def resize_bilinear_align_corners(x, out_size):
     return (top * wy0[:, None] + bot * wy1[:, None]).astype(F32)
 
 
-def project_points(pc, trans_mat, map_size=MAP_SIZE):
+def project_points(pc, trans_mat, map_size=MAP_SIZE, clamp_hi=136.0):
     """network/modules.py:37-47: homogeneous matmul, perspective divide (+1e-8),
-    clamp to [0,136] (hard-coded), normalise by (map_size-1)/2."""
+    clamp to [0,136] (hard-coded in the reference; `clamp_hi` generalises it for larger maps,
+    BASELINE config 5), normalise by (map_size-1)/2."""
     pc = np.asarray(pc, dtype=F32)
     T = np.asarray(trans_mat, dtype=F32)
     # torch.matmul on CPU evaluates the K=4 dot product as an fma chain in k order
@@ -72,7 +73,7 @@ def project_points(pc, trans_mat, map_size=MAP_SIZE):
     with np.errstate(divide="ignore", invalid="ignore"):
         xy = (xyz[:, :, :2] / (xyz[:, :, 2:3] + F32(1e-8))).astype(F32)
     # torch.clamp propagates NaN, np.clip does too
-    xy = np.clip(xy, F32(0.0), F32(136.0)).astype(F32)
+    xy = np.clip(xy, F32(0.0), F32(clamp_hi)).astype(F32)
     half = F32((map_size - 1) / 2.0)
     grid = ((xy - half) / half).astype(F32)
     return xy, grid
@@ -110,9 +111,9 @@ def grid_sample_2d(f, grid):
     return out
 
 
-def perceptual_pooling(img_featuremaps, pc, trans_mat, map_size=MAP_SIZE):
+def perceptual_pooling(img_featuremaps, pc, trans_mat, map_size=MAP_SIZE, clamp_hi=136.0):
     """PerceptualPooling.forward, network/modules.py:24-54 -> [B,1024,1,N]."""
-    _, grid = project_points(pc, trans_mat, map_size)
+    _, grid = project_points(pc, trans_mat, map_size, clamp_hi)
     outs = [grid_sample_2d(resize_bilinear_align_corners(m, map_size), grid)
             for m in img_featuremaps]
     return np.concatenate(outs, axis=1)[:, :, None, :]
@@ -207,11 +208,12 @@ def voxel_decoder2(p, feat, percep_feat, weights):
     return mlp(concat_features(p, feat, percep_feat), weights)
 
 
-def list_query(query, img_featuremaps, vox_feat, trans_mat, weights, pre_permuted=False):
+def list_query(query, img_featuremaps, vox_feat, trans_mat, weights, pre_permuted=False,
+               map_size=MAP_SIZE, clamp_hi=136.0):
     """The per-point part of LIST.forward, network/models.py:91-97 -> sdf [B,N]."""
     q = np.asarray(query, dtype=F32) if pre_permuted else permute_scale_query(query)
     B, N, _ = q.shape
-    percep = perceptual_pooling(img_featuremaps, q, trans_mat).reshape(B, -1, N)
+    percep = perceptual_pooling(img_featuremaps, q, trans_mat, map_size, clamp_hi).reshape(B, -1, N)
     return voxel_decoder2(q, vox_feat, percep, weights)
 
 

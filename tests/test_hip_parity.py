@@ -321,3 +321,45 @@ def test_full_size_properties(hip, full_case):
     print(f"full-size subset fp16 max-abs err {err16:.3e}; fp16 vs bf16x3 over all points "
           f"{float((sdf16 - sdf).abs().max()):.3e}")
     assert err16 < TOL_FP16 and float((sdf16 - sdf).abs().max()) < TOL_FP16
+
+
+# ------------------------------------------------------------------------------------------ other BASELINE configs
+def test_config5_highres_maps(hip):
+    """BASELINE config 5 shapes: 512^2 images (maps 512..32 px), map_size 274, clamp 273, at B=1."""
+    seed, B, N = 555, 1, 3000
+    c = {"query": synth.make_query(seed, B, N), "img_maps": synth.make_img_maps(seed, B, 512),
+         "vox_maps": synth.make_vox_maps(seed, B, 64), "weights": synth.make_mlp_weights(seed)}
+    T = synth.make_trans_mat(seed, B) * np.float32(273.0 / 136.0)
+    T[:, :, 2] *= np.float32(136.0 / 273.0)
+    img = hip.prep_img_maps([dev(m) for m in c["img_maps"]], 274)
+    vox = hip.prep_vox_maps([dev(m) for m in c["vox_maps"]])
+    packed = hip.prep_mlp_weights({k: dev(v) for k, v in c["weights"].items()}, vox.channels, img.channels)
+    sdf = hip.sdf_query(dev(c["query"]), dev(T), img, vox, packed, clamp_hi=273.0).cpu().numpy()
+    idx = np.arange(0, N, 6)
+    ref = O.list_query(c["query"][:, idx], c["img_maps"], c["vox_maps"], T, c["weights"],
+                       map_size=274, clamp_hi=273.0)
+    err = np.abs(sdf[:, idx] - ref).max()
+    print(f"config-5 shapes max-abs err {err:.3e}")
+    assert err < TOL_X3
+
+
+def test_config4_grid_inference_chunks(hip):
+    """BASELINE config 4: one image, a dense query grid processed in 262144-row chunks inside the
+    library.  128^3 = 2M grid points here (the 256^3 run is the same code path, 8x longer);
+    chunking must be invisible and a subset must match the oracle."""
+    c = cases.build_case("real")
+    img, vox, packed = prepare(hip, c)
+    res = 128
+    from list_amd import utils
+    grid = utils.grid_points_on_device(-0.5, 0.5, res, "cuda:0").unsqueeze(0)        # [1, res^3, 3]
+    T = dev(c["trans_mat"])
+    whole = hip.sdf_query(grid, T, img, vox, packed)
+    assert torch.isfinite(whole).all()
+    part = torch.cat([hip.sdf_query(grid[:, s:s + 300000], T, img, vox, packed)
+                      for s in range(0, res ** 3, 300000)], 1)
+    assert torch.equal(whole, part)
+    idx = np.random.RandomState(3).choice(res ** 3, 200, replace=False)
+    ref = O.list_query(grid[:, idx].cpu().numpy(), c["img_maps"], c["vox_maps"], c["trans_mat"], c["weights"])
+    err = np.abs(whole.cpu().numpy()[:, idx] - ref).max()
+    print(f"grid-inference subset max-abs err {err:.3e}")
+    assert err < TOL_X3
