@@ -30,18 +30,24 @@ def _f32(t):
 
 
 class _Cache:
-    """Remembers the last prepared object for a tuple of source tensors (same storage, same
-    version counter => same content), e.g. across the chunk loop of executors.LIST.test."""
+    """Remembers the last prepared object for a tuple of source tensors, e.g. across the chunk loop
+    of executors.LIST.test.  A hit needs the SAME tensor objects (held strongly here, so neither
+    their ids nor their storage can be recycled by a later, different tensor) with unchanged
+    version counters; anything else -- new encoder outputs, an in-place update, an optimizer
+    step -- rebuilds."""
 
     def __init__(self):
-        self.key, self.value = None, None
+        self.sources, self.versions, self.value = None, None, None
 
     def get(self, tensors, make):
-        key = tuple((t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.device.index)
-                    for t in tensors)
-        if key != self.key:
+        tensors = tuple(tensors)
+        versions = tuple(t._version for t in tensors)
+        hit = (self.sources is not None and len(self.sources) == len(tensors)
+               and all(a is b for a, b in zip(self.sources, tensors)) and versions == self.versions)
+        if not hit:
+            self.sources, self.versions, self.value = None, None, None     # drop the old maps first
             self.value = make()
-            self.key = key
+            self.sources, self.versions = tensors, versions
         return self.value
 
 

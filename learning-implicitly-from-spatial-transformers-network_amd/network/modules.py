@@ -26,9 +26,9 @@ class PerceptualPooling(nn.Module):
         self._caches = {}
 
     def prepared(self, img_featuremaps):
-        maps = [m.detach().float() for m in img_featuremaps]
         return self._caches.setdefault("img", hotpath._Cache()).get(
-            maps, lambda: hip.prep_img_maps(maps, self.map_size))
+            list(img_featuremaps),
+            lambda: hip.prep_img_maps([m.detach().float() for m in img_featuremaps], self.map_size))
 
     def forward(self, img_featuremaps, pc, trans_mat):
         hotpath.require_hip(pc, "PerceptualPooling.forward(pc)")

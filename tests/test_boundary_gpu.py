@@ -64,6 +64,23 @@ def test_module_level_calls_equal_fused(net):
     net.cpu()
 
 
+def test_prepared_map_cache_is_not_fooled_by_address_reuse(net):
+    """Fresh encoder outputs usually land on the addresses of the freed previous ones (same shapes,
+    version 0): the prepared-map cache must key on tensor identity, not on data_ptr."""
+    net.to(DEV)
+    q = torch.from_numpy(synth.make_query(9, 1, 300)).to(DEV)
+    outs = []
+    with torch.no_grad():
+        for seed in (11, 12, 11):
+            img = torch.from_numpy(synth.uniform(seed, (1, 3, 64, 64))).to(DEV)
+            feat_l2, vox_feat, tm, _, _ = net.encode(img)
+            outs.append(net.query_sdf(q, feat_l2, vox_feat, tm).clone())
+            del feat_l2, vox_feat, tm, img           # let the allocator recycle the blocks
+    assert not torch.equal(outs[0], outs[1])          # different image -> different field
+    assert (outs[0] - outs[2]).abs().max() < 1e-5     # same image again -> same field (MIOpen noise only)
+    net.cpu()
+
+
 def test_gradients_flow_through_the_query(net):
     net.to(DEV)
     img = torch.from_numpy(synth.uniform(78, (2, 3, 64, 64))).to(DEV)
