@@ -76,6 +76,8 @@ def build_parser():
     # --- MI355X path
     p.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp16", "bf16"],
                    help="arithmetic of the implicit MLP on the HIP path")
+    p.add_argument("--channels_last", type=_bool, default=True,
+                   help="run the encoders that feed the query path in channels-last memory format")
     p.add_argument("--synthetic_len", type=int, default=64, help="items per epoch of the synthetic datasets")
     p.add_argument("--num_workers", type=int, default=0)
     p.add_argument("--max_steps", type=int, default=0, help="stop training after this many batches (0 = off)")

@@ -173,13 +173,78 @@ static bool try_prep_img_tile(const ListMap2D& m, int B, int ms, int Ct, int cof
   return true;
 }
 
+// Channels-last source (sc == 1, e.g. a ResNet run with memory_format=torch.channels_last): no
+// transposition is needed -- every thread resizes 4 (fp32 out) or 8 (fp16 out) consecutive channels
+// of one output pixel from four coalesced 16/32-B tap reads.  Same arithmetic as k_prep_img.
+template <int F16>
+__global__ __launch_bounds__(256) void k_prep_img_nhwc(ListMap2D m, int B, int ms, int Ct, int coff,
+                                                       void* __restrict__ out) {
+  constexpr int VO = F16 ? 8 : 4;
+  const int Q = m.C / VO;
+  const int64_t total = (int64_t)B * ms * ms * Q;
+  const float sy = ms > 1 ? (float)(m.H - 1) / (float)(ms - 1) : 0.f;
+  const float sx = ms > 1 ? (float)(m.W - 1) / (float)(ms - 1) : 0.f;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int q = (int)(idx % Q);
+    int64_t t = idx / Q;
+    const int x = (int)(t % ms); t /= ms;
+    const int y = (int)(t % ms);
+    const int b = (int)(t / ms);
+    const float fy = sy * (float)y, fx = sx * (float)x;
+    const int y0 = min((int)fy, m.H - 1), x0 = min((int)fx, m.W - 1);
+    const int y1 = y0 + (y0 < m.H - 1 ? 1 : 0), x1 = x0 + (x0 < m.W - 1 ? 1 : 0);
+    const float wy1 = fy - (float)y0, wy0 = 1.f - wy1, wx1 = fx - (float)x0, wx0 = 1.f - wx1;
+    const float* base = m.data + (int64_t)b * m.sb + q * VO;
+    const float* p00 = base + (int64_t)y0 * m.sh + (int64_t)x0 * m.sw;
+    const float* p01 = base + (int64_t)y0 * m.sh + (int64_t)x1 * m.sw;
+    const float* p10 = base + (int64_t)y1 * m.sh + (int64_t)x0 * m.sw;
+    const float* p11 = base + (int64_t)y1 * m.sh + (int64_t)x1 * m.sw;
+    float o[VO];
+#pragma unroll
+    for (int h = 0; h < VO / 4; ++h) {
+      const float4 v00 = *(const float4*)(p00 + 4 * h), v01 = *(const float4*)(p01 + 4 * h);
+      const float4 v10 = *(const float4*)(p10 + 4 * h), v11 = *(const float4*)(p11 + 4 * h);
+      o[4 * h + 0] = (v00.x * wx0 + v01.x * wx1) * wy0 + (v10.x * wx0 + v11.x * wx1) * wy1;
+      o[4 * h + 1] = (v00.y * wx0 + v01.y * wx1) * wy0 + (v10.y * wx0 + v11.y * wx1) * wy1;
+      o[4 * h + 2] = (v00.z * wx0 + v01.z * wx1) * wy0 + (v10.z * wx0 + v11.z * wx1) * wy1;
+      o[4 * h + 3] = (v00.w * wx0 + v01.w * wx1) * wy0 + (v10.w * wx0 + v11.w * wx1) * wy1;
+    }
+    const int64_t oi = ((int64_t)(b * ms + y) * ms + x) * Ct + coff + q * VO;
+    if (F16) {
+      const uint2 lo = half4(make_float4(o[0], o[1], o[2], o[3]));
+      const uint2 hi = half4(make_float4(o[VO - 4], o[VO - 3], o[VO - 2], o[VO - 1]));
+      *(uint4*)((unsigned short*)out + oi) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    } else {
+      *(float4*)((float*)out + oi) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+static bool try_prep_img_nhwc(const ListMap2D& m, int B, int ms, int Ct, int coff, int f16, void* out,
+                              hipStream_t s, hipError_t* e) {
+  const int vo = f16 ? 8 : 4;
+  if (m.sc != 1 || (m.C % vo) != 0 || (coff % vo) != 0 || (Ct % vo) != 0 || (m.sw % 4) != 0 ||
+      (m.sh % 4) != 0 || (m.sb % 4) != 0 || (reinterpret_cast<uintptr_t>(m.data) & 15) != 0)
+    return false;
+  const int64_t total = (int64_t)B * ms * ms * (m.C / vo);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  if (f16)
+    hipLaunchKernelGGL(k_prep_img_nhwc<1>, dim3((unsigned)blocks), dim3(256), 0, s, m, B, ms, Ct, coff, out);
+  else
+    hipLaunchKernelGGL(k_prep_img_nhwc<0>, dim3((unsigned)blocks), dim3(256), 0, s, m, B, ms, Ct, coff, out);
+  *e = hipGetLastError();
+  return true;
+}
+
 hipError_t launch_prep_img(const ListMap2D maps[LIST_N_IMG_LEVELS], int B, int map_size, int Ct,
                            int f16, void* out, hipStream_t s) {
   int coff = 0;
   for (int i = 0; i < LIST_N_IMG_LEVELS; ++i) {
     const ListMap2D& m = maps[i];
     hipError_t fe = hipSuccess;
-    if (try_prep_img_tile(m, B, map_size, Ct, coff, f16, out, s, &fe)) {
+    if (try_prep_img_nhwc(m, B, map_size, Ct, coff, f16, out, s, &fe) ||
+        try_prep_img_tile(m, B, map_size, Ct, coff, f16, out, s, &fe)) {
       if (fe != hipSuccess) return fe;
       coff += m.C;
       continue;

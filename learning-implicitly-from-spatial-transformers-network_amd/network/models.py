@@ -28,6 +28,10 @@ class LIST(nn.Module):
         self.bb_min, self.bb_max = config.bb_min, config.bb_max
         enc_feat_size = sum(config.im_enc_layers[3:]) * 7 + 1024 + 3          # 3610
 
+        # MI355X-first producer layout: the encoders whose maps feed the query path run
+        # channels-last, so their outputs already have the [..spatial..][C] layout the gathers read and
+        # list_prep_vox_maps is a no-op (MIOpen NDHWC/NHWC convolutions: same results, same speed).
+        self.channels_last = bool(getattr(config, "channels_last", True))
         self.vox_encoder = M.VoxelEncoder2(config.im_enc_layers)
         self.sdf_decoder = M.VoxelDecoder2(enc_feat_size, 256)
         self.sdf_decoder.precision = getattr(config, "precision", "bf16x3")
@@ -43,9 +47,19 @@ class LIST(nn.Module):
             nn.Linear(128, 12))
 
     # ---- per-image stage (encoders, coarse cloud, camera, voxel pyramid) ---------------------------
+    def _apply_memory_format(self, img):
+        if self.channels_last and img.is_cuda:
+            if not getattr(self, "_cl_done", False):
+                self.vox_encoder.to(memory_format=torch.channels_last_3d)
+                self.im_encoder2.to(memory_format=torch.channels_last)
+                self._cl_done = True
+            return img.contiguous(memory_format=torch.channels_last), True
+        return img, False
+
     def encode(self, img, trans_mat=None):
         feat_g, _ = self.im_encoder(img)
-        feat_g2, feat_l2 = self.im_encoder2(img)
+        img_cl, use_cl = self._apply_memory_format(img)
+        feat_g2, feat_l2 = self.im_encoder2(img_cl)
         pc = self.point_decoder([feat_g.unsqueeze(1)])
         coarse = torch.max(self.point_mlp_coarse(pc), -1)[0].reshape(img.shape[0], -1)
         if trans_mat is None:
@@ -53,6 +67,9 @@ class LIST(nn.Module):
             trans_mat = self.spatial_transformer(code).reshape(-1, 4, 3)
         occ = self.create_occ(pc)
         vox_feat = self.vox_encoder(occ)
+        if use_cl:      # MIOpen keeps the format; levels that lost it would simply be transposed again
+            vox_feat = [v if v.shape[1] == 1 else v.contiguous(memory_format=torch.channels_last_3d)
+                        for v in vox_feat]
         return feat_l2, vox_feat, trans_mat, pc, occ
 
     # ---- per-point stage: the HIP hot path ------------------------------------------------------------

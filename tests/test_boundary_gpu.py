@@ -64,6 +64,23 @@ def test_module_level_calls_equal_fused(net):
     net.cpu()
 
 
+def test_encoders_emit_channels_last_maps_used_in_place(net):
+    """the model's producers hand the query path channels-last maps, so the 3-D layout
+    hand-off is zero-copy (the prepared levels alias the encoder outputs)."""
+    from list_amd import hip
+    net.to(DEV)
+    img = torch.from_numpy(synth.uniform(78, (2, 3, 64, 64))).to(DEV)
+    with torch.no_grad():
+        feat_l2, vox_feat, tm, _, _ = net.encode(img)
+    assert all(f.stride(1) == 1 for f in feat_l2)                       # NHWC image maps
+    vox = hip.prep_vox_maps(vox_feat)
+    for l, v in enumerate(vox_feat):
+        if v.shape[1] > 1 and v.shape[2] > 1:
+            assert v.is_contiguous(memory_format=torch.channels_last_3d)
+            assert vox.levels[l].data == v.data_ptr()
+    net.cpu()
+
+
 def test_prepared_map_cache_is_not_fooled_by_address_reuse(net):
     """Fresh encoder outputs usually land on the addresses of the freed previous ones (same shapes,
     version 0): the prepared-map cache must key on tensor identity, not on data_ptr."""

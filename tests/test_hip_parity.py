@@ -144,6 +144,17 @@ def test_prep_vox_accepts_channels_last_in_place(hip):
     np.testing.assert_array_equal(sdf_cl, sdf)
 
 
+def test_prep_img_channels_last_source_is_bit_identical(hip):
+    c = cases.build_case("small")
+    nchw = [dev(m) for m in c["img_maps"]]
+    nhwc = [t.contiguous(memory_format=torch.channels_last) for t in nchw]
+    assert nhwc[0].stride(1) == 1
+    for md in ("f32", "f16"):
+        a = hip.prep_img_maps(nchw, dtype=md).data
+        b = hip.prep_img_maps(nhwc, dtype=md).data
+        assert torch.equal(a, b)
+
+
 def test_prep_img_matches_oracle_resize(hip):
     c = cases.build_case("small")
     img = hip.prep_img_maps([dev(m) for m in c["img_maps"]])
