@@ -599,42 +599,42 @@ __device__ __forceinline__ void put(const GatherParams& g, int64_t o, float v) {
   store_feat1<FMT>(g.x_hi, g.x_lo, o, v);
 }
 
+// 8 lanes per point: lane j < 7 samples stencil point j of every scalar level (8 taps in flight),
+// lane 7 writes xyz and the zero padding.
 template <int FMT>
 __global__ __launch_bounds__(256) void k_gather_tail(GatherParams g, TailLevels tl, int xyz_off,
                                                      int F) {
-  const int row = blockIdx.x * 256 + threadIdx.x;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int row = t >> 3, j = t & 7;
   if (row >= g.rows) return;
   const Pt p = load_point(g, row);
   const int64_t ro = (int64_t)row * g.Kp;
-  for (int l = 0; l < tl.n; ++l) {
-    const ListVoxLevel& lv = tl.lv[l];
-    const float* __restrict__ base = (const float*)lv.data + (int64_t)p.b * lv.image_stride;
-    Taps t[LIST_N_STENCIL];
-    float v[LIST_N_STENCIL][8];
+  if (j < LIST_N_STENCIL) {
+    const float x = p.x + (j == 1 ? -kDisp : j == 2 ? kDisp : 0.f);
+    const float y = p.y + (j == 3 ? -kDisp : j == 4 ? kDisp : 0.f);
+    const float z = p.z + (j == 5 ? -kDisp : j == 6 ? kDisp : 0.f);
+    for (int l = 0; l < tl.n; ++l) {
+      const ListVoxLevel& lv = tl.lv[l];
+      const float* __restrict__ base = (const float*)lv.data + (int64_t)p.b * lv.image_stride;
+      const Taps tp = make_taps(x, y, z, 1, lv.D, lv.H, lv.W);
+      float v[8];
 #pragma unroll
-    for (int j = 0; j < LIST_N_STENCIL; ++j) {
-      const float x = p.x + (j == 1 ? -kDisp : j == 2 ? kDisp : 0.f);
-      const float y = p.y + (j == 3 ? -kDisp : j == 4 ? kDisp : 0.f);
-      const float z = p.z + (j == 5 ? -kDisp : j == 6 ? kDisp : 0.f);
-      t[j] = make_taps(x, y, z, 1, lv.D, lv.H, lv.W);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[j][k] = base[t[j].o[k]];       // all 56 loads before any use
+      for (int k = 0; k < 8; ++k) v[k] = base[tp.o[k]];
+      put<FMT>(g, ro + tl.off[l] + j, p.valid ? reduce_taps1(v, tp) : 0.f);
     }
-#pragma unroll
-    for (int j = 0; j < LIST_N_STENCIL; ++j)
-      put<FMT>(g, ro + tl.off[l] + j, p.valid ? reduce_taps1(v[j], t[j]) : 0.f);
+    return;
   }
   put<FMT>(g, ro + xyz_off + 0, p.valid ? p.x : 0.f);     // p_features, modules.py:257
   put<FMT>(g, ro + xyz_off + 1, p.valid ? p.y : 0.f);
   put<FMT>(g, ro + xyz_off + 2, p.valid ? p.z : 0.f);
   // zero padding up to Kp (a multiple of 64, rows are 128-B aligned): widen the stores as the
   // alignment allows -- 6 stores instead of 38 for F = 3610 (uniform control flow: F, Kp are uniform)
-  auto zero_pad = [&](unsigned short* __restrict__ x) {
+  auto zero_pad = [&](unsigned short* __restrict__ xp) {
     int k = F;
-    if ((k & 1) && k < g.Kp) { x[ro + k] = 0; k += 1; }
-    if ((k & 2) && k + 2 <= g.Kp) { *(unsigned*)(x + ro + k) = 0u; k += 2; }
-    if ((k & 4) && k + 4 <= g.Kp) { *(uint2*)(x + ro + k) = make_uint2(0u, 0u); k += 4; }
-    for (; k + 8 <= g.Kp; k += 8) *(uint4*)(x + ro + k) = make_uint4(0u, 0u, 0u, 0u);
+    if ((k & 1) && k < g.Kp) { xp[ro + k] = 0; k += 1; }
+    if ((k & 2) && k + 2 <= g.Kp) { *(unsigned*)(xp + ro + k) = 0u; k += 2; }
+    if ((k & 4) && k + 4 <= g.Kp) { *(uint2*)(xp + ro + k) = make_uint2(0u, 0u); k += 4; }
+    for (; k + 8 <= g.Kp; k += 8) *(uint4*)(xp + ro + k) = make_uint4(0u, 0u, 0u, 0u);
   };
   zero_pad(g.x_hi);
   if (FMT == FMT_BF16_SPLIT) zero_pad(g.x_lo);
@@ -705,7 +705,7 @@ static hipError_t launch_gather_fmt(const GatherParams& g, const FeatLayout& L, 
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   mark(LIST_STAGE_IMG);
-  hipLaunchKernelGGL(k_gather_tail<FMT>, dim3((g.rows + 255) / 256), dim3(256), 0, s, g, tl, L.xyz_off,
+  hipLaunchKernelGGL(k_gather_tail<FMT>, dim3((g.rows + 31) / 32), dim3(256), 0, s, g, tl, L.xyz_off,
                      L.F);
   return hipGetLastError();
 }

@@ -246,6 +246,7 @@ size_t list_query_workspace_bytes(int64_t n_points, int32_t F, int32_t H1, int32
 
 int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
   FeatLayout L;
+  if (a && a->B >= 0 && a->N >= 0 && (int64_t)a->B * a->N == 0) return LIST_OK;   // empty query: nothing to do
   int rc = check_query_common(a, &L);
   if (rc != LIST_OK) return rc;
   if (!a->sdf || !a->packed_mlp) return fail(LIST_ERR_ARG, "sdf/packed_mlp is NULL");

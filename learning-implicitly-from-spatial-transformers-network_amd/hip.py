@@ -330,6 +330,9 @@ def sdf_query(query, trans_mat, img, vox, packed, perm=(2, 1, 0), scale=2.0, pre
 
     stage_events: optional ctypes array (c_void_p * N_STAGES) of hipEvent_t handles."""
     lib = load()
+    if query.dim() == 3 and query.shape[0] * query.shape[1] == 0:      # empty query -> empty field
+        _f32_cuda(query, "query")
+        return torch.empty(query.shape[:2], dtype=torch.float32, device=query.device)
     a, keep = _fill_query_args(query, perm, scale, vox, packed, precision, trans_mat, img, percep_feat,
                                clamp_hi)
     a.no_sort = 0 if sort_points else 1

@@ -274,6 +274,21 @@ def test_chunked_workspace_is_bit_identical(hip):
     assert lib.list_sdf_query_fwd(C.byref(a), None) == -3
 
 
+def test_empty_and_single_point_queries(hip, golden_dir):
+    c = cases.build_case("tiny")
+    g = golden(golden_dir, "tiny")
+    img, vox, packed = prepare(hip, c)
+    T = dev(c["trans_mat"])
+    empty = hip.sdf_query(dev(c["query"])[:, :0], T, img, vox, packed)
+    assert tuple(empty.shape) == (2, 0)
+    import ctypes as C
+    a, keep = hip._fill_query_args(dev(c["query"])[:, :1], (2, 1, 0), 2.0, vox, packed, "bf16x3", T, img)
+    a.N = 0
+    assert hip.load().list_sdf_query_fwd(C.byref(a), None) == 0           # C ABI: empty query is a no-op
+    one = hip.sdf_query(dev(c["query"])[:, :1].contiguous(), T, img, vox, packed).cpu().numpy()
+    assert np.abs(one - g["sdf"][:, :1]).max() < TOL_X3                    # a single ragged row per image
+
+
 def test_error_paths(hip):
     c = cases.build_case("tiny")
     with pytest.raises(RuntimeError, match="float32"):
