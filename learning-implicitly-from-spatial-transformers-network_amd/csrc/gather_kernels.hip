@@ -377,7 +377,9 @@ __device__ __forceinline__ unsigned spread3(unsigned v) {      // 4 bits -> ever
 
 struct SortParams { int b_first; int pixel; const float* trans_mat; int ms; float clamp_hi; };
 
-__device__ __forceinline__ int sort_key(const GatherParams& g, const SortParams& sp, int i) {
+struct SortKeys { int morton; int pixel; };
+
+__device__ __forceinline__ SortKeys sort_keys(const GatherParams& g, const SortParams& sp, int i) {
   const int64_t gp = g.p_begin + i;
   const int b = (int)(gp / g.N);
   const int n = (int)(gp - (int64_t)b * g.N);
@@ -386,12 +388,13 @@ __device__ __forceinline__ int sort_key(const GatherParams& g, const SortParams&
   const float py = q[(int64_t)g.perm1 * g.q_sc] * g.scale;
   const float pz = q[(int64_t)g.perm2 * g.q_sc] * g.scale;
   const int slot = (b - sp.b_first) % kSortImages;
+  SortKeys k;
+  k.pixel = 0;
   if (sp.pixel) {
     const Proj pr = project(sp.trans_mat + b * 12, px, py, pz, sp.ms, 1, sp.clamp_hi);
     const int pix = pr.o00;                               // y0 * ms + x0 (Ct = 1)
     const int y0 = pix / sp.ms, x0 = pix - y0 * sp.ms;
-    const int cell = min(y0 * ((sp.ms + 3) / 4) + (x0 >> 2), kSortPixCells - 1);
-    return slot * kSortPixCells + cell;
+    k.pixel = slot * kSortPixCells + min(y0 * ((sp.ms + 3) / 4) + (x0 >> 2), kSortPixCells - 1);
   }
   const float pc[3] = {px, py, pz};
   unsigned c[3];
@@ -400,28 +403,35 @@ __device__ __forceinline__ int sort_key(const GatherParams& g, const SortParams&
     const float v = (pc[a] + 1.f) * (0.5f * kSortCellsPerAxis);
     c[a] = (unsigned)fminf(fmaxf(v, 0.f), (float)(kSortCellsPerAxis - 1));
   }
-  const unsigned m = spread3(c[0]) | (spread3(c[1]) << 1) | (spread3(c[2]) << 2);
-  return slot * kSortCells + (int)m;
+  k.morton = slot * kSortCells + (int)(spread3(c[0]) | (spread3(c[1]) << 1) | (spread3(c[2]) << 2));
+  return k;
 }
 
-__global__ __launch_bounds__(256) void k_sort_hist(GatherParams g, SortParams sp, int* __restrict__ keys,
-                                                   int* __restrict__ bins) {
+// Both orders are built by the same three launches: bins = [Morton counters | pixel counters].
+__global__ __launch_bounds__(256) void k_sort_hist(GatherParams g, SortParams sp, int* __restrict__ keys_m,
+                                                   int* __restrict__ keys_p, int* __restrict__ bins_m,
+                                                   int* __restrict__ bins_p) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= g.n_valid) return;
-  const int k = sort_key(g, sp, i);
-  keys[i] = k;
-  atomicAdd(&bins[k], 1);
+  const SortKeys k = sort_keys(g, sp, i);
+  keys_m[i] = k.morton;
+  atomicAdd(&bins_m[k.morton], 1);
+  if (sp.pixel) { keys_p[i] = k.pixel; atomicAdd(&bins_p[k.pixel], 1); }
 }
 
-// Exclusive scan of the counters, one workgroup per image slot.  The number of points of every
-// slot is known on the host (points per image is fixed), so each slot's base offset arrives as an
-// argument and the slots scan independently: `cells` (4096 or 8192) counters, 1024 threads.
+// Exclusive scan of the counters, one workgroup per (order, image slot).  The number of points of
+// every slot is known on the host (points per image is fixed), so each slot's base offset arrives as
+// an argument and the slots scan independently: `cells` (4096 or 8192) counters, 1024 threads.
 struct SlotBase { int base[kSortImages]; };
 
-__global__ __launch_bounds__(1024) void k_sort_scan(int* __restrict__ bins, int cells, SlotBase sb) {
+__global__ __launch_bounds__(1024) void k_sort_scan(int* __restrict__ bins_m, int* __restrict__ bins_p,
+                                                    int nslots, SlotBase sb) {
   __shared__ int part[1024];
+  const bool pix = (int)blockIdx.x >= nslots;
+  const int slot = pix ? blockIdx.x - nslots : blockIdx.x;
+  const int cells = pix ? kSortPixCells : kSortCells;
   const int per = cells / 1024;                        // 4 or 8 consecutive counters per thread
-  int* mine = bins + (int64_t)blockIdx.x * cells + threadIdx.x * per;
+  int* mine = (pix ? bins_p : bins_m) + (int64_t)slot * cells + threadIdx.x * per;
   int c[8];
   int sum = 0;
 #pragma unroll
@@ -434,35 +444,43 @@ __global__ __launch_bounds__(1024) void k_sort_scan(int* __restrict__ bins, int 
     part[threadIdx.x] += v;
     __syncthreads();
   }
-  int run = sb.base[blockIdx.x] + part[threadIdx.x] - sum;
+  int run = sb.base[slot] + part[threadIdx.x] - sum;
 #pragma unroll
   for (int i = 0; i < 8; ++i)
     if (i < per) { mine[i] = run; run += c[i]; }
 }
 
-// order[pos] = i and, if wanted, inverse[i] = pos
-__global__ __launch_bounds__(256) void k_sort_scatter(int n_valid, const int* __restrict__ keys,
-                                                      int* __restrict__ bins, int* __restrict__ order,
-                                                      int* __restrict__ inverse) {
+// order[pos] = i (Morton) with its inverse row_of[i] = pos, and order_img[pos'] = i (pixel order)
+__global__ __launch_bounds__(256) void k_sort_scatter(int n_valid, const int* __restrict__ keys_m,
+                                                      const int* __restrict__ keys_p, int* __restrict__ bins_m,
+                                                      int* __restrict__ bins_p, int* __restrict__ order,
+                                                      int* __restrict__ row_of, int* __restrict__ order_img) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_valid) return;
-  const int pos = atomicAdd(&bins[keys[i]], 1);
+  const int pos = atomicAdd(&bins_m[keys_m[i]], 1);
   order[pos] = i;
-  if (inverse) inverse[i] = pos;
+  if (order_img) {
+    row_of[i] = pos;
+    order_img[atomicAdd(&bins_p[keys_p[i]], 1)] = i;
+  }
 }
 
-static hipError_t sort_pass(const GatherParams& g, const SortParams& sp, int cells, int* keys, int* bins,
-                            int* order, int* inverse, hipStream_t s) {
+hipError_t launch_sort_points(const GatherParams& g, const ListQueryArgs& a, const SortBuffers& sb,
+                              hipStream_t s) {
+  SortParams sp;
+  sp.b_first = (int)(g.p_begin / g.N);
+  const bool img = a.percep_feat == nullptr && sb.order_img != nullptr &&
+                   a.map_size * ((a.map_size + 3) / 4) <= kSortPixCells;
+  sp.pixel = img ? 1 : 0; sp.trans_mat = a.trans_mat; sp.ms = a.map_size; sp.clamp_hi = a.clamp_hi;
   const int64_t b_last = (g.p_begin + g.n_valid - 1) / g.N;
   const int nslots = (int)((b_last - sp.b_first + 1 < kSortImages) ? (b_last - sp.b_first + 1) : kSortImages);
-  const int nbins = nslots * cells;
-  hipError_t e = hipMemsetAsync(bins, 0, (size_t)nbins * sizeof(int), s);
+  int* bins_m = sb.bins;
+  int* bins_p = sb.bins + (size_t)nslots * kSortCells;
+  const size_t nbins = (size_t)nslots * (kSortCells + (img ? kSortPixCells : 0));
+  hipError_t e = hipMemsetAsync(sb.bins, 0, nbins * sizeof(int), s);
   if (e != hipSuccess) return e;
-  const unsigned nb = (unsigned)((g.n_valid + 255) / 256);
-  GatherParams raw = g;
-  raw.order = nullptr;
   // points per slot: image b of the chunk goes to slot (b - b_first) % kSortImages
-  SlotBase sb;
+  SlotBase base;
   int cnt[kSortImages] = {0};
   const int64_t p_end = g.p_begin + g.n_valid;
   for (int64_t b = sp.b_first; b <= b_last; ++b) {
@@ -471,24 +489,16 @@ static hipError_t sort_pass(const GatherParams& g, const SortParams& sp, int cel
     cnt[(b - sp.b_first) % kSortImages] += (int)(hi - lo);
   }
   int run = 0;
-  for (int i = 0; i < kSortImages; ++i) { sb.base[i] = run; run += cnt[i]; }
-  hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(256), 0, s, raw, sp, keys, bins);
-  hipLaunchKernelGGL(k_sort_scan, dim3(nslots), dim3(1024), 0, s, bins, cells, sb);
-  hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(256), 0, s, g.n_valid, keys, bins, order, inverse);
+  for (int i = 0; i < kSortImages; ++i) { base.base[i] = run; run += cnt[i]; }
+  const unsigned nb = (unsigned)((g.n_valid + 255) / 256);
+  GatherParams raw = g;
+  raw.order = nullptr;
+  int* keys_m = sb.keys;
+  hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(256), 0, s, raw, sp, keys_m, sb.keys2, bins_m, bins_p);
+  hipLaunchKernelGGL(k_sort_scan, dim3(img ? 2 * nslots : nslots), dim3(1024), 0, s, bins_m, bins_p, nslots, base);
+  hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(256), 0, s, g.n_valid, keys_m, sb.keys2, bins_m, bins_p,
+                     sb.order, img ? sb.row_of : nullptr, img ? sb.order_img : nullptr);
   return hipGetLastError();
-}
-
-hipError_t launch_sort_points(const GatherParams& g, const ListQueryArgs& a, const SortBuffers& sb,
-                              hipStream_t s) {
-  SortParams sp;
-  sp.b_first = (int)(g.p_begin / g.N);
-  sp.pixel = 0; sp.trans_mat = nullptr; sp.ms = 0; sp.clamp_hi = 0.f;
-  const bool img = a.percep_feat == nullptr && sb.order_img != nullptr &&
-                   a.map_size * ((a.map_size + 3) / 4) <= kSortPixCells;
-  hipError_t e = sort_pass(g, sp, kSortCells, sb.keys, sb.bins, sb.order, img ? sb.row_of : nullptr, s);
-  if (e != hipSuccess || !img) return e;
-  sp.pixel = 1; sp.trans_mat = a.trans_mat; sp.ms = a.map_size; sp.clamp_hi = a.clamp_hi;
-  return sort_pass(g, sp, kSortPixCells, sb.keys, sb.bins, sb.order_img, nullptr, s);
 }
 
 // grid = rows/64, block = 256: the workgroup walks its 64 points, lanes over channel quads.  The 64

@@ -282,7 +282,8 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
     if (!a->no_sort) {
       SortBuffers sb;
       sb.order = (int*)(wsb + ws.order); sb.order_img = (int*)(wsb + ws.order_img);
-      sb.row_of = (int*)(wsb + ws.row_of); sb.keys = (int*)(wsb + ws.keys); sb.bins = (int*)(wsb + ws.bins);
+      sb.row_of = (int*)(wsb + ws.row_of); sb.keys = (int*)(wsb + ws.keys);
+      sb.keys2 = (int*)(wsb + ws.keys2); sb.bins = (int*)(wsb + ws.bins);
       e = launch_sort_points(g, *a, sb, s);
       if (e != hipSuccess) return hip_fail(e, "sort launch");
       g.order = sb.order;

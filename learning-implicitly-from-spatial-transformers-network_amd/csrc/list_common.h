@@ -174,16 +174,16 @@ constexpr int kSortCellsPerAxis = 16;                        // Morton cells per
 constexpr int kSortCells = kSortCellsPerAxis * kSortCellsPerAxis * kSortCellsPerAxis;   // 4096
 constexpr int kSortImages = 64;                              // image slots in the key (b % 64)
 constexpr int kSortPixCells = 8192;                          // pixel-order bins per image (>= ms * ceil(ms/4))
-constexpr int kSortBins = kSortPixCells * kSortImages;       // 524288 counters (2 MB)
+constexpr int kSortBins = (kSortCells + kSortPixCells) * kSortImages;   // Morton + pixel counters (3 MB)
 
 struct Workspace {
   size_t x_hi, x_lo, h1_hi, h1_lo, h2_hi, h2_lo;     // byte offsets
   size_t order, keys, bins;                          // point sort: int32 [rows], [rows], [kSortBins]
-  size_t order_img, row_of;                          // pixel order for the 2-D gather; point -> X row
+  size_t order_img, row_of, keys2;                   // pixel order for the 2-D gather; point -> X row
   size_t total;
 };
 inline size_t workspace_row_bytes(int Kp, int H1, int H2) {
-  return (size_t)2 * 2 * ((size_t)Kp + H1 + H2) + 16;
+  return (size_t)2 * 2 * ((size_t)Kp + H1 + H2) + 20;
 }
 inline size_t workspace_fixed_bytes() { return (size_t)kSortBins * 4 + 16 * 256; }
 inline Workspace workspace_layout(int64_t rows, int Kp, int H1, int H2) {
@@ -195,6 +195,7 @@ inline Workspace workspace_layout(int64_t rows, int Kp, int H1, int H2) {
   w.h2_hi = take((size_t)rows * H2 * 2); w.h2_lo = take((size_t)rows * H2 * 2);
   w.order = take((size_t)rows * 4); w.keys = take((size_t)rows * 4);
   w.order_img = take((size_t)rows * 4); w.row_of = take((size_t)rows * 4);
+  w.keys2 = take((size_t)rows * 4);
   w.bins = take((size_t)kSortBins * 4);
   w.total = o;
   return w;
@@ -238,7 +239,7 @@ hipError_t launch_prep_weights(const ListMlpWeights& w, const FeatLayout& L, con
                                char* packed, hipStream_t s);
 hipError_t launch_split(const float* x, unsigned short* hi, unsigned short* lo, int64_t n, int fmt,
                         hipStream_t s);
-struct SortBuffers { int* order; int* order_img; int* row_of; int* keys; int* bins; };
+struct SortBuffers { int* order; int* order_img; int* row_of; int* keys; int* keys2; int* bins; };
 hipError_t launch_sort_points(const GatherParams& g, const ListQueryArgs& a, const SortBuffers& sb,
                               hipStream_t s);
 hipError_t launch_gather(const GatherParams& g, const FeatLayout& L, const ListQueryArgs& a,

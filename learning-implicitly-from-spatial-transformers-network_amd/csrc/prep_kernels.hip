@@ -422,6 +422,22 @@ hipError_t launch_split(const float* x, unsigned short* hi, unsigned short* lo, 
   return hipGetLastError();
 }
 
+// biases, w3, b3: five short fp32 vectors, one launch
+__global__ __launch_bounds__(256) void k_copy_small(const float* b0, const float* b1, const float* b2,
+                                                    const float* w3, const float* b3, int H1, int H2, int H3,
+                                                    float* o0, float* o1, float* o2, float* o3, float* o4) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < H1) { o0[i] = b0[i]; return; }
+  i -= H1;
+  if (i < H2) { o1[i] = b1[i]; return; }
+  i -= H2;
+  if (i < H3) { o2[i] = b2[i]; return; }
+  i -= H3;
+  if (i < H3) { o3[i] = w3[i]; return; }
+  i -= H3;
+  if (i == 0) o4[0] = b3[0];
+}
+
 hipError_t launch_prep_weights(const ListMlpWeights& w, const FeatLayout& L, const PackedMlp& P,
                                char* packed, hipStream_t s) {
   const int64_t n0 = (int64_t)w.H1 * L.Kp;
@@ -436,13 +452,12 @@ hipError_t launch_prep_weights(const ListMlpWeights& w, const FeatLayout& L, con
   e = launch_split(w.w2, (unsigned short*)(packed + P.w2_hi), (unsigned short*)(packed + P.w2_lo),
                    (int64_t)w.H3 * w.H2, fmt, s);
   if (e != hipSuccess) return e;
-  const struct { size_t off; const float* src; size_t n; } cp[] = {
-      {P.b0, w.b0, (size_t)w.H1}, {P.b1, w.b1, (size_t)w.H2}, {P.b2, w.b2, (size_t)w.H3},
-      {P.w3, w.w3, (size_t)w.H3}, {P.b3, w.b3, 1}};
-  for (const auto& c : cp) {
-    e = hipMemcpyAsync(packed + c.off, c.src, c.n * sizeof(float), hipMemcpyDeviceToDevice, s);
-    if (e != hipSuccess) return e;
-  }
+  hipLaunchKernelGGL(k_copy_small, dim3((unsigned)((w.H1 + w.H2 + 2 * w.H3 + 1 + 255) / 256)), dim3(256), 0, s,
+                     w.b0, w.b1, w.b2, w.w3, w.b3, w.H1, w.H2, w.H3, (float*)(packed + P.b0),
+                     (float*)(packed + P.b1), (float*)(packed + P.b2), (float*)(packed + P.w3),
+                     (float*)(packed + P.b3));
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
   return hipSuccess;
 }
 
