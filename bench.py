@@ -43,7 +43,9 @@ class HipEvents:
     """hipEvent_t through ctypes (torch.cuda.Event exposes no stable raw handle before record)."""
 
     def __init__(self):
-        self.rt = ctypes.CDLL("libamdhip64.so")
+        # the HIP runtime instance torch already loaded (never a second copy of the runtime)
+        path = next((l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l), "libamdhip64.so")
+        self.rt = ctypes.CDLL(path)
         self.rt.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
         self.rt.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         self.rt.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p,
