@@ -13,6 +13,12 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _built_library():
+    import __graft_entry__ as ge
+    ge.build()                      # no-op when csrc/liblist_hip.so is up to date
+
+
 @pytest.fixture(scope="module")
 def cfg():
     return arguments.default_config(vox_res=32, train_batch_size=2)

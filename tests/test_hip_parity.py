@@ -25,6 +25,8 @@ TOL_BF16 = 5e-3
 
 @pytest.fixture(scope="module")
 def hip():
+    import __graft_entry__ as ge
+    ge.build()                      # no-op when csrc/liblist_hip.so is up to date
     from list_amd import hip as h
     h.load()
     assert torch.cuda.is_available(), "the gpu-marked tests need a GPU"
