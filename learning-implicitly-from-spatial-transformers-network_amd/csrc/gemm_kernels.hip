@@ -264,10 +264,172 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(GemmParams p) {
   }
 }
 
+// ---- the same kernel on the 16x16x32 MFMA shape -----------------------------------------------------
+// Identical tiling, staging and pipeline; the wave's 128x64 outputs are 8x4 tiles of 16x16 (4
+// accumulator registers each).  Operand lane map: lane l holds A[row l&15][k = 8*(l>>4) .. +7] of a
+// 16x32 block; C/D: col = lane&15, row = 4*(lane>>4) + reg.  (MI355X holds a higher clock on this
+// shape under sustained MFMA load; launch_one dispatches whichever shape measured faster per epilogue.)
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+
+template <int FP16>
+__device__ __forceinline__ f32x4v mfma16(const bf16x8& a, const bf16x8& b, const f32x4v& c) {
+  if (FP16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b),
+                                                  c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int TERMS, int EPI, int FP16>
+__global__ __launch_bounds__(512, 2) void k_gemm_nt16(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int tiles_n = p.N / BN;
+  const int ntiles = (p.M / BM) * tiles_n;
+  const int tile = xcd_contiguous_block(blockIdx.x, ntiles);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+
+  f32x4v acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+  using P = Pipe<TERMS>;
+  const int frow = lane & 15, fq = lane >> 4;
+  const int fswz = P::swz(frow);                       // tile row offsets are multiples of 16
+  const int a_row_off = (wm * 128 + frow) * P::kRowBytes;
+  const int w_row_off = (wn * 64 + frow) * P::kRowBytes;
+
+  const int nk = p.K / P::BK;
+#pragma unroll
+  for (int s = 0; s < P::kAhead; ++s)
+    if (s < nk) stage_tiles<TERMS>(p, smem + s * P::kStageBytes, m0, n0, s * P::kRowBytes, wave, lane);
+  for (int t = 0; t < nk; ++t) {
+    const int younger = min(P::kAhead - 1, nk - 1 - t);
+    if (younger >= 2) wait_vmcnt<2 * P::kLoadsPerStage>();
+    else if (younger == 1) wait_vmcnt<P::kLoadsPerStage>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (t + P::kAhead < nk)
+      stage_tiles<TERMS>(p, smem + ((t + P::kAhead) % P::kStages) * P::kStageBytes, m0, n0,
+                         (t + P::kAhead) * P::kRowBytes, wave, lane);
+    const char* cur = smem + (t % P::kStages) * P::kStageBytes;
+#pragma unroll
+    for (int s2 = 0; s2 < P::BK / 32; ++s2) {
+      const int coff = ((4 * s2 + fq) ^ fswz) << 4;
+      bf16x8 ah[8], al[8], wh[4], wl[4];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        ah[i] = *(const bf16x8*)(cur + a_row_off + i * 16 * P::kRowBytes + coff);
+        if (TERMS == 3)
+          al[i] = *(const bf16x8*)(cur + P::kPlaneBytes + a_row_off + i * 16 * P::kRowBytes + coff);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        wh[j] = *(const bf16x8*)(cur + P::kWOff + w_row_off + j * 16 * P::kRowBytes + coff);
+        if (TERMS == 3)
+          wl[j] = *(const bf16x8*)(cur + P::kWOff + P::kPlaneBytes + w_row_off + j * 16 * P::kRowBytes + coff);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (TERMS == 3) {
+            acc[i][j] = mfma16<0>(al[i], wh[j], acc[i][j]);
+            acc[i][j] = mfma16<0>(ah[i], wl[j], acc[i][j]);
+          }
+          acc[i][j] = mfma16<FP16>(ah[i], wh[j], acc[i][j]);
+        }
+    }
+  }
+
+  const int col_in = lane & 15, row_in = 4 * (lane >> 4);
+  if (EPI == EPI_RELU_SPLIT || EPI == EPI_F32) {
+    const int ld = EPI == EPI_F32 ? p.N : p.ldo;
+    const int64_t lane_off = (int64_t)(m0 + wm * 128 + row_in) * ld + n0 + wn * 64 + col_in;
+    float* of = EPI == EPI_F32 ? p.out_f32 + lane_off : nullptr;
+    unsigned short* oh = EPI == EPI_F32 ? nullptr : p.out_hi + lane_off;
+    unsigned short* ol = (EPI == EPI_F32 || !p.out_lo) ? nullptr : p.out_lo + lane_off;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float bias = p.bias ? p.bias[n0 + wn * 64 + j * 16 + col_in] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int off = (i * 16 + e) * ld + j * 16;
+          float v = acc[i][j][e] + bias;
+          if (EPI == EPI_F32) {
+            if (p.relu) v = fmaxf(v, 0.f);
+            of[off] = v;
+          } else {
+            v = fmaxf(v, 0.f);
+            const unsigned short h = to_half_plane<FP16>(v);
+            oh[off] = h;
+            if (!FP16 && ol) ol[off] = f2bf(v - bf2f(h));
+          }
+        }
+    }
+  } else {
+    float part[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) part[i][e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = wn * 64 + j * 16 + col_in;      // n0 == 0 (N == BN)
+      const float bias = p.bias[col], w3 = p.w3[col];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[i][e] += fmaxf(acc[i][j][e] + bias, 0.f) * w3;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = part[i][e];
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 1);
+        part[i][e] = v;
+      }
+    __syncthreads();
+    float* red = (float*)smem;                         // [4 (wn)][256 rows]
+    if (col_in == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wn * 256 + wm * 128 + i * 16 + row_in + e] = part[i][e];
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+      const int row = m0 + threadIdx.x;
+      if (row < p.n_valid) {
+        const int rl = threadIdx.x;
+        p.sdf[p.order ? p.order[row] : row] =
+            ((red[rl] + red[256 + rl]) + (red[512 + rl] + red[768 + rl])) + p.b3[0];
+      }
+    }
+  }
+}
+
 template <int TERMS, int EPI, int FP16>
 static hipError_t launch_one(const GemmParams& p, hipStream_t s) {
   const int ntiles = (p.M / BM) * (p.N / BN);
-  hipLaunchKernelGGL((k_gemm_nt<TERMS, EPI, FP16>), dim3(ntiles), dim3(512), 0, s, p);
+  // measured (fp16, P = 160k): the two shapes tie on fc_0 (0.58 ms, the kernel is bound by the LDS-DMA
+  // path, not by the MFMA clock); 32x32 has the cheaper 64-B store runs (fc_1 0.074 vs 0.086 ms), 16x16
+  // the cheaper row reduction of the fused fc_2 + fc_out epilogue (0.045 vs 0.058 ms)
+  if (EPI == EPI_RELU_DOT)
+    hipLaunchKernelGGL((k_gemm_nt16<TERMS, EPI, FP16>), dim3(ntiles), dim3(512), 0, s, p);
+  else
+    hipLaunchKernelGGL((k_gemm_nt<TERMS, EPI, FP16>), dim3(ntiles), dim3(512), 0, s, p);
   return hipGetLastError();
 }
 
