@@ -161,6 +161,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(GemmParams p) {
           wl[buf][j] = *(const bf16x8*)(cur + P::kWOff + P::kPlaneBytes + w_row_off + j * 32 * P::kRowBytes + coff);
       }
     };
+#ifdef LIST_GEMM_NO_FRAGS
+    continue;        // ablation: LDS-DMA stream + barrier only
+#endif
     load_frags(0, 0);
 #pragma unroll
     for (int s2 = 0; s2 < NS; ++s2) {
