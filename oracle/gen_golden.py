@@ -101,7 +101,51 @@ def main():
         displacements=dec.displacments.numpy(),
     )
     print("aux written")
+    grad_goldens(torch, dec, pool)
     model_goldens(torch)
+
+
+GRAD_CASES = ("tiny", "small", "edge")
+GRAD_W0_ROW_STEP = 8
+
+
+def grad_goldens(torch, dec, pool):
+    """Backward of the path: gradients of  sum(sdf * g)  w.r.t. every differentiable input,
+    taken by autograd THROUGH THE REFERENCE's modules (PerceptualPooling.forward + VoxelDecoder2.forward +
+    the glue of models.py:91-97).  g = synth.normalish(seed 9000 + case index)."""
+    from . import cases, synth
+    for ci, name in enumerate(GRAD_CASES):
+        c = cases.build_case(name)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).clone().requires_grad_(True)
+        dec.load_state_dict({"fc." + k: torch.from_numpy(v.copy()) for k, v in c["weights"].items()})
+        dec.zero_grad()
+        query = torch.from_numpy(c["query"].copy())
+        img_maps = [t(m) for m in c["img_maps"]]
+        vox_maps = [t(m) for m in c["vox_maps"]]
+        T = t(c["trans_mat"])
+        q = query[:, :, [2, 1, 0]] * 2
+        B, N, _ = q.shape
+        percep = pool(img_maps, q, T)
+        sdf = dec(q, vox_maps, percep.reshape(B, -1, N))
+        g = torch.from_numpy(synth.normalish(9000 + ci, (B, N)))
+        (sdf * g).sum().backward()
+        out = {"grad_sdf": g.numpy(), "d_trans_mat": T.grad.numpy()}
+        for i, m in enumerate(img_maps):
+            out[f"d_img{i}"] = m.grad.numpy()
+        for i, m in enumerate(vox_maps):
+            out[f"d_vox{i}"] = m.grad.numpy()
+        for k, v in dec.state_dict(keep_vars=True).items():
+            out["d_" + k[3:] if k.startswith("fc.") else "d_" + k] = v.grad.numpy()
+        # keep the fixtures small: every 8th output row of fc_0's weight gradient, and for the larger
+        # case every 2nd voxel / pixel of the map gradients (the tests apply the same slicing)
+        out["d_fc_0.weight"] = out["d_fc_0.weight"][::GRAD_W0_ROW_STEP]
+        if name == "small":
+            for i in range(len(vox_maps)):
+                out[f"d_vox{i}"] = out[f"d_vox{i}"][:, :, ::2, ::2, ::2]
+            for i in range(len(img_maps)):
+                out[f"d_img{i}"] = out[f"d_img{i}"][:, :, ::2, ::2]
+        np.savez_compressed(os.path.join(OUT, f"hotpath_grad_{name}.npz"), **out)
+        print("grad", name, {k: float(np.abs(v).max()) for k, v in out.items() if k.startswith("d_fc") or k == "d_trans_mat"})
 
 
 def _harness_resnet18(pretrained=False, **kw):
@@ -155,4 +199,9 @@ def model_goldens(torch):
 
 
 if __name__ == "__main__":
-    main()
+    if "--grads-only" in sys.argv:
+        _torch, _M, _L, _U, _dec = _import_reference()
+        _torch.set_num_threads(8)
+        grad_goldens(_torch, _dec, _M.PerceptualPooling())
+    else:
+        main()

@@ -57,6 +57,28 @@ def list_query(query, img_maps, vox_maps, trans_mat, weights, pre_permuted=False
     return implicit_mlp(feats, weights)
 
 
+def list_query_grads(query, img_maps, vox_maps, trans_mat, weights, grad_sdf, pre_permuted=False):
+    """Backward of the path by autograd over the same op sequence (the reference trains through
+    exactly these ops, train.py:82-85): gradients of sum(sdf * grad_sdf) w.r.t. the 2-D maps, the 3-D
+    maps, trans_mat and the MLP parameters.  Returns (sdf, dict)."""
+    with torch.enable_grad():
+        leaf = lambda x: x.detach().clone().requires_grad_(True)
+        img_l = [leaf(m) for m in img_maps]
+        vox_l = [leaf(m) for m in vox_maps]
+        T = leaf(trans_mat)
+        W = {k: leaf(v) for k, v in weights.items()}
+        pts = query if pre_permuted else query[:, :, [2, 1, 0]] * 2
+        percep = pooled_image_features(img_l, pts, T)
+        feats = torch.cat((stencil_voxel_features(pts, vox_l), percep, pts.transpose(1, 2)), dim=1)
+        sdf = implicit_mlp(feats, W)
+        (sdf * grad_sdf).sum().backward()
+    grads = {"d_trans_mat": T.grad}
+    grads.update({f"d_img{i}": m.grad for i, m in enumerate(img_l)})
+    grads.update({f"d_vox{i}": m.grad for i, m in enumerate(vox_l)})
+    grads.update({"d_" + k: v.grad for k, v in W.items()})
+    return sdf.detach(), grads
+
+
 def to_torch(case):
     """numpy case dict (oracle/cases.py) -> torch tensors."""
     t = lambda a: torch.from_numpy(a.copy())
