@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LIST_ABI_VERSION 1
+#define LIST_ABI_VERSION 2
 
 #define LIST_N_IMG_LEVELS 5   /* ResEncoder feature maps, network/modules.py:1067 */
 #define LIST_N_VOX_LEVELS 6   /* VoxelEncoder2 feature maps, network/modules.py:425-442 */
@@ -216,6 +216,80 @@ int list_gemm_nt(const void* a_hi, const void* a_lo, const void* w_hi, const voi
 int list_split_bf16(const float* x, void* hi, void* lo, int64_t n, void* stream);
 /* fp32 -> fp16 (round-to-nearest-even, saturating at +-65504). n % 4 == 0. */
 int list_to_fp16(const float* x, void* out, int64_t n, void* stream);
+
+/* =======================================================================================
+ * Backward of the path (training step; the reference differentiates these ops with autograd:
+ * train.py:82-85 through models.py:91-97, modules.py:24-54 and modules.py:255-282).
+ *
+ * list_sdf_query_bwd takes d(loss)/d(sdf) and produces the gradients of every trainable input of
+ * the path: the MLP parameters (reference layout), the prepared perceptual map, the voxel levels,
+ * and trans_mat.  Query coordinates are data in the reference's training loop and get no gradient.
+ *
+ * Contract with the forward: `fwd` are the arguments of a list_sdf_query_fwd call that has been
+ * enqueued before on the same stream, with fwd->workspace UNTOUCHED since (it holds the feature
+ * matrix, the hidden activations and the point order), and the whole query in ONE row chunk
+ * (B*N <= 262144 and workspace_bytes >= list_query_workspace_bytes(B*N)).  fwd->percep_feat must be
+ * NULL (the fused form).  Arithmetic follows fwd->precision: BF16X3 keeps every gradient operand as
+ * bf16 hi+lo (fp32-grade), FP16 scales d(sdf) by a power of two into the fp16 range (undone in the
+ * fp32 epilogues), BF16 rounds gradient operands to bf16.  All sums are fp32.
+ * Outputs are OVERWRITTEN (not accumulated); a NULL output is skipped.  Map and trans_mat
+ * gradients use fp32 atomics where contributions collide, so their last bits may differ run to run;
+ * the MLP parameter gradients are bitwise reproducible.
+ */
+typedef struct ListMlpGrads {         /* reference layouts, like ListMlpWeights */
+  float* w0; float* b0;               /* [H1,F], [H1] */
+  float* w1; float* b1;               /* [H2,H1], [H2] */
+  float* w2; float* b2;               /* [H3,H2], [H3] */
+  float* w3; float* b3;               /* [1,H3], [1] */
+} ListMlpGrads;
+
+typedef struct ListQueryGradArgs {
+  const ListQueryArgs* fwd;           /* see the contract above */
+  const float* grad_sdf;              /* [B,N] contiguous: d(loss)/d(sdf) */
+  const void* packed_mlp_bwd;         /* from list_prep_mlp_weights_bwd (transposed copies) */
+  ListMlpGrads mlp;                   /* any pointer may be NULL */
+  float* grad_img_map;                /* [B][map_size][map_size][img_C] fp32 (gradient of the map    */
+                                      /*   list_prep_img_maps produced), or NULL                      */
+  float* grad_trans_mat;              /* [B,4,3] fp32, or NULL */
+  ListVoxLevel grad_vox[LIST_N_VOX_LEVELS];   /* fp32 channels-last [B][D][H][W][C] buffers (dtype    */
+                                      /*   LIST_MAP_F32, data written through); data == NULL: skipped */
+  void* workspace; size_t workspace_bytes;    /* >= list_query_bwd_workspace_bytes() */
+  void* const* stage_events;          /* optional: LIST_N_BWD_STAGES hipEvent_t handles */
+} ListQueryGradArgs;
+
+enum ListBwdStage {
+  LIST_BWD_BEGIN = 0,
+  LIST_BWD_HEAD = 1,      /* scale, fc_2 re-evaluation, d(fc_out), bias/w3 sums */
+  LIST_BWD_WGRAD2 = 2,    /* k_gemm_tn: dW2 */
+  LIST_BWD_DGRAD2 = 3,    /* k_gemm_nt: dH2 (masked) */
+  LIST_BWD_WGRAD1 = 4,
+  LIST_BWD_DGRAD1 = 5,
+  LIST_BWD_WGRAD0 = 6,    /* k_gemm_tn: dW0 [512 x 3648], the large one */
+  LIST_BWD_DGRAD0 = 7,    /* k_gemm_nt: dX [P x 3648] */
+  LIST_BWD_VOX = 8,       /* scatter-add into the voxel levels */
+  LIST_BWD_IMG = 9,       /* gradient of the prepared perceptual map */
+  LIST_BWD_TRANS = 10,    /* gradient of trans_mat */
+  LIST_N_BWD_STAGES = 11
+};
+
+size_t list_packed_mlp_bwd_bytes(const ListMlpWeights* w);
+int list_prep_mlp_weights_bwd(const ListMlpWeights* w, void* packed_bwd, size_t packed_bytes, void* stream);
+size_t list_query_bwd_workspace_bytes(int64_t n_points, int32_t F, int32_t H1, int32_t H2, int32_t H3,
+                                      int32_t precision);
+int list_sdf_query_bwd(const ListQueryGradArgs* args, void* stream);
+
+/* Adjoint of list_prep_img_maps (the bilinear align_corners resize + concat of modules.py:26-35,53):
+ * the gradient of the prepared map -> one gradient per encoder level.  grads[i].data (float32, written
+ * through the given strides, every element overwritten) must describe [B,C_i,H_i,W_i]. */
+int list_img_map_grad_to_levels(const float* grad_img_map, int32_t B, int32_t map_size,
+                                const ListMap2D grads[LIST_N_IMG_LEVELS], void* stream);
+
+/* list_gemm_tn -- test/diagnostic entry for the transposed-operand MFMA kernel of the weight
+ * gradients: out[M][N] = sum_p A[p][m] * B[p][n], A [P][M] and B [P][N] given as 16-bit planes like
+ * list_gemm_nt.  M % 256 == 0, N % 8 == 0, P % 256 == 0. */
+int list_gemm_tn(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* out,
+                 void* slab, size_t slab_bytes, int32_t M, int32_t N, int32_t P, int32_t precision,
+                 void* stream);
 
 const char* list_last_error(void);
 int list_abi_version(void);

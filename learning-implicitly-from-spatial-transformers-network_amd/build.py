@@ -11,7 +11,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(CSRC, "liblist_hip.so")
-SOURCES = ["prep_kernels.hip", "gather_kernels.hip", "gemm_kernels.hip", "list_capi.hip"]
+SOURCES = ["prep_kernels.hip", "gather_kernels.hip", "gemm_kernels.hip", "bwd_mlp_kernels.hip",
+           "bwd_scatter_kernels.hip", "list_capi.hip"]
+HEADERS = ["list_common.h", "point_math.h"]
+OBJ_DIR = os.path.join(CSRC, "_obj")
 ARCH = "gfx950"
 
 
@@ -19,8 +22,7 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "list_common.h"),
-                                                         os.path.join(INCLUDE, "list_hip.h")]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.join(INCLUDE, "list_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -32,17 +34,37 @@ def build(force=False, verbose=False):
         raise RuntimeError("hipcc not found: cannot build liblist_hip.so")
     # -ffp-contract=off: coordinates and interpolation weights must round exactly like the
     # reference's CPU ops (an fma of "scale*x - floor" skips a rounding); fmaf is explicit where wanted
-    cmd = [hipcc, "-O3", "-std=c++17", "-ffp-contract=off"] + os.environ.get("LIST_HIPCC_FLAGS", "").split() + [ f"--offload-arch={ARCH}", "-fPIC", "-shared",
-           "-I", INCLUDE, "-I", CSRC] + [os.path.join(CSRC, s) for s in SOURCES]
+    flags = ["-O3", "-std=c++17", "-ffp-contract=off"] + os.environ.get("LIST_HIPCC_FLAGS", "").split() + [
+        f"--offload-arch={ARCH}", "-fPIC", "-I", INCLUDE, "-I", CSRC]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    tag = f".{os.getpid()}"
+
+    def compile_one(src):
+        obj = os.path.join(OBJ_DIR, src.replace(".hip", tag + ".o"))
+        cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return obj, r
+
+    # one translation unit per worker (the files are independent; hipcc itself is single-threaded)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
+        results = list(ex.map(compile_one, SOURCES))
+    objs = [o for o, _ in results]
     tmp = LIB + f".tmp{os.getpid()}"
-    cmd += ["-o", tmp]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        if os.path.exists(tmp):
-            os.remove(tmp)
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    try:
+        for (_, r), src in zip(results, SOURCES):
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed on {src}:\n" + r.stdout + r.stderr)
+        r = subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC"] + objs + ["-o", tmp],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
+    finally:
+        for o in objs:
+            if os.path.exists(o):
+                os.remove(o)
     os.replace(tmp, LIB)            # atomic: concurrent readers never see a half-written library
     return LIB
 

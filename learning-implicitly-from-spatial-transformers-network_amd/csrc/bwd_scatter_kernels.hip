@@ -1,0 +1,794 @@
+// Backward of the gathers: dX [rows][Kp] (gradient of the feature matrix, gather order) ->
+//   * gradients of the channels-last voxel levels     (adjoint of F.grid_sample 3-D, modules.py:263-265)
+//   * gradient of the prepared 137^2 perceptual map   (adjoint of F.grid_sample 2-D, modules.py:46-52)
+//   * gradient of trans_mat                           (through modules.py:37-45: matmul, divide, clamp)
+//   * gradients of the five encoder maps              (adjoint of F.interpolate, modules.py:26-35)
+// HBM / atomic-rate bound (global float atomics run at ~1.3 TB/s chip-wide on MI355X), so the design
+// goal is FEWER atomics, shaped as 256-B runs along the channel axis:
+//   * coarse voxel levels: the rows are in Morton order, so the 64 points of a workgroup touch a small
+//     box of voxels; their 64 x 7 x 8 tap contributions are first summed in an LDS window (ds_add_f32)
+//     and the window is flushed once (10-60x fewer global atomics); fine levels whose box does not fit
+//     go straight to global atomics, lanes over channels;
+//   * perceptual map: no atomics at all -- the points are already in pixel order (forward's second sort),
+//     so every map pixel GATHERS the contributions of the <= 4 pixel cells around it and is written once.
+#include <limits.h>
+
+#include "list_common.h"
+#include "point_math.h"
+
+namespace list {
+
+template <int DXH>
+__device__ __forceinline__ float dx_at(const void* __restrict__ dx, int64_t i) {
+  return DXH ? h2f(((const unsigned short*)dx)[i]) : ((const float*)dx)[i];
+}
+
+__device__ __forceinline__ void stencil_rt(const Pt& p, int j, float& x, float& y, float& z) {
+  x = p.x + (j == 1 ? -kDisp : j == 2 ? kDisp : 0.f);
+  y = p.y + (j == 3 ? -kDisp : j == 4 ? kDisp : 0.f);
+  z = p.z + (j == 5 ? -kDisp : j == 6 ? kDisp : 0.f);
+}
+
+// ---- voxel levels ----------------------------------------------------------------------------------------
+constexpr int kScatterRows = 64;           // points per workgroup (consecutive rows = one Morton neighbourhood)
+
+// Straight to memory: C lanes per (point, stencil point) item, one 4*C-byte atomic run per tap.  This is
+// what the levels whose stencil spreads over many voxels use (128^3 .. 32^3): their 56 taps per point are
+// all distinct and neighbouring points share few of them, so the cost is the chip's atomic byte rate.
+template <int C, int DXH, int T = 256>
+__device__ __forceinline__ void scatter_direct(const ScatterParams& sp, const ListVoxLevel& gv, int col_off,
+                                               const Pt* __restrict__ pts, int r_begin, int r_end,
+                                               int64_t row0, float inv_s) {
+  constexpr int per_pass = T / C;
+  const int tid = threadIdx.x;
+  const int c = tid % C;
+  float* __restrict__ gout = (float*)gv.data;
+  for (int it = r_begin * LIST_N_STENCIL + tid / C; it < r_end * LIST_N_STENCIL; it += per_pass) {
+    const int r = it / LIST_N_STENCIL, j = it - r * LIST_N_STENCIL;
+    const Pt p = pts[r];
+    if (!p.valid) continue;
+    float x, y, z;
+    stencil_rt(p, j, x, y, z);
+    const Taps t = make_taps(x, y, z, C, gv.D, gv.H, gv.W);
+    const float gval = dx_at<DXH>(sp.dx, (row0 + r) * sp.g.Kp + col_off + j * C + c) * inv_s;
+    float* base = gout + (int64_t)p.b * gv.image_stride + c;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) atomicAdd(base + t.o[k], t.w[k] * gval);
+  }
+}
+
+template <int C, int DXH>
+__global__ __launch_bounds__(256) void k_scatter_vox(ScatterParams sp, ListVoxLevel gv, int col_off) {
+  __shared__ Pt pts[kScatterRows];
+  const int blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  if (threadIdx.x < kScatterRows) pts[threadIdx.x] = load_point(sp.g, blk * kScatterRows + threadIdx.x);
+  __syncthreads();
+  scatter_direct<C, DXH>(sp, gv, col_off, pts, 0, kScatterRows, (int64_t)blk * kScatterRows, sp.scale[1]);
+}
+
+// Coarse levels (stencil shorter than a voxel: 16^3 and 8^3, 58 % of all tap contributions): a run of
+// Morton-consecutive points touches a small box of voxels, so its contributions are summed in an LDS
+// window first and the window is flushed once (8-50x fewer global atomics).  LDS float atomics are slow on
+// CDNA (measured ~2.6 clk per LANE), so the window is accumulated WITHOUT atomics: thread (copy k,
+// channel c) owns column c of copy k of the window and is the only one that ever touches it -- plain
+// ds_read / add / ds_write, the 8 taps of a sample per batch.  A tap that the border clamp folds onto
+// its neighbour (weight exactly 0) is redirected to a dummy cell so the 8 addresses of a batch never alias.
+// The workgroup's 64 points are cut into runs adaptively: 8-point boxes are merged greedily while the
+// merged box fits the window (8^3 level: ~32 points per run, 16^3: ~16); a box that does not fit on its
+// own goes straight to memory.
+constexpr int kWinFloats = 18432;          // 72 KB window: two workgroups per CU
+constexpr int kSubPts = 8;                 // granularity of the run planner = points per tap-record chunk
+constexpr int kNSub = kScatterRows / kSubPts;
+struct TapRec { int o[8]; float w[8]; };
+struct Run { int first, count, direct; int ox, oy, oz, nx, ny, nz, b; };
+
+template <int C, int DXH>
+__global__ __launch_bounds__((C >= 128 ? C : 128)) void k_scatter_vox_win(ScatterParams sp, ListVoxLevel gv,
+                                                                             int col_off) {
+  constexpr int T = C >= 128 ? C : 128;
+  constexpr int COPIES = T / C;
+  constexpr int MYP = kSubPts / COPIES;              // points per copy per chunk
+  constexpr int kCap = kWinFloats / T - 1;           // window voxels (one more cell is the dummy)
+  static_assert(C >= 16 && T % C == 0 && kSubPts % COPIES == 0 && T >= kScatterRows &&
+                T >= kSubPts * LIST_N_STENCIL, "geometry");
+  __shared__ Pt pts[kScatterRows];
+  __shared__ int box[kNSub][8];                      // lo x,y,z | hi x,y,z | min image | max image
+  __shared__ Run runs[kNSub];
+  __shared__ int n_runs;
+  __shared__ TapRec taps[kSubPts * LIST_N_STENCIL];
+  __shared__ float win[kWinFloats];
+  const int tid = threadIdx.x;
+  const int c = tid % C, k = tid / C;
+  const int blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int W = gv.W, H = gv.H, D = gv.D;
+  const int64_t row0 = (int64_t)blk * kScatterRows;
+  const float inv_s = sp.scale[1];
+  if (tid < kNSub * 8) box[tid >> 3][tid & 7] = ((tid & 7) < 3 || (tid & 7) == 6) ? INT_MAX : INT_MIN;
+  if (tid < kScatterRows) pts[tid] = load_point(sp.g, blk * kScatterRows + tid);
+  __syncthreads();
+  if (tid < kScatterRows && pts[tid].valid) {
+    const Pt p = pts[tid];
+    int* bx = box[tid / kSubPts];
+    const Axis lx = axis_setup(p.x - kDisp, W), hx = axis_setup(p.x + kDisp, W);
+    const Axis ly = axis_setup(p.y - kDisp, H), hy = axis_setup(p.y + kDisp, H);
+    const Axis lz = axis_setup(p.z - kDisp, D), hz = axis_setup(p.z + kDisp, D);
+    atomicMin(&bx[0], lx.i0); atomicMin(&bx[1], ly.i0); atomicMin(&bx[2], lz.i0);
+    atomicMax(&bx[3], hx.i0 + hx.has1); atomicMax(&bx[4], hy.i0 + hy.has1); atomicMax(&bx[5], hz.i0 + hz.has1);
+    atomicMin(&bx[6], p.b); atomicMax(&bx[7], p.b);
+  }
+  __syncthreads();
+  if (tid == 0) {                                    // plan the runs
+    int n = 0, i = 0;
+    while (i < kNSub) {
+      if (box[i][7] < box[i][6]) { ++i; continue; }  // no valid point
+      int lo[3] = {box[i][0], box[i][1], box[i][2]}, hi[3] = {box[i][3], box[i][4], box[i][5]};
+      const int b = box[i][6];
+      Run r;
+      r.first = i * kSubPts; r.count = kSubPts; r.b = b;
+      const int64_t v0 = (int64_t)(hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1);
+      r.direct = (box[i][6] != box[i][7] || v0 > kCap) ? 1 : 0;
+      int jn = i + 1;
+      while (!r.direct && jn < kNSub && box[jn][7] >= box[jn][6] && box[jn][6] == b && box[jn][7] == b) {
+        int l2[3], h2[3];
+        for (int a = 0; a < 3; ++a) { l2[a] = min(lo[a], box[jn][a]); h2[a] = max(hi[a], box[jn][3 + a]); }
+        const int64_t v = (int64_t)(h2[0] - l2[0] + 1) * (h2[1] - l2[1] + 1) * (h2[2] - l2[2] + 1);
+        if (v > kCap) break;
+        for (int a = 0; a < 3; ++a) { lo[a] = l2[a]; hi[a] = h2[a]; }
+        r.count += kSubPts; ++jn;
+      }
+      r.ox = lo[0]; r.oy = lo[1]; r.oz = lo[2];
+      r.nx = hi[0] - lo[0] + 1; r.ny = hi[1] - lo[1] + 1; r.nz = hi[2] - lo[2] + 1;
+      runs[n++] = r;
+      i = jn;
+    }
+    n_runs = n;
+  }
+  __syncthreads();
+  float* __restrict__ gout = (float*)gv.data;
+  const int nr = n_runs;
+#pragma unroll 1
+  for (int ri = 0; ri < nr; ++ri) {
+    const Run r = runs[ri];
+    if (r.direct) {
+      scatter_direct<C, DXH, T>(sp, gv, col_off, pts, r.first, r.first + r.count, row0, inv_s);
+      continue;
+    }
+    const int nx = r.nx, ny = r.ny, vol = r.nx * r.ny * r.nz;
+    float* mine = win + (k * (vol + 1)) * C + c;     // my column of my copy
+    for (int v = 0; v <= vol; ++v) mine[v * C] = 0.f;
+#pragma unroll 1
+    for (int ch = 0; ch < r.count; ch += kSubPts) {
+      __syncthreads();                               // previous chunk's tap records are consumed
+      if (tid < kSubPts * LIST_N_STENCIL) {
+        const int pl = tid / LIST_N_STENCIL, j = tid - pl * LIST_N_STENCIL;
+        const Pt p = pts[r.first + ch + pl];
+        float x, y, z;
+        stencil_rt(p, j, x, y, z);
+        const Axis ax = axis_setup(x, W), ay = axis_setup(y, H), az = axis_setup(z, D);
+        const int o000 = ((az.i0 - r.oz) * ny + (ay.i0 - r.oy)) * nx + (ax.i0 - r.ox);
+        TapRec t;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const bool ux = q & 1, uy = q & 2, uz = q & 4;
+          const bool off = (ux && !ax.has1) || (uy && !ay.has1) || (uz && !az.has1) || !p.valid;
+          const float w = (ux ? ax.w1 : ax.w0) * (uy ? ay.w1 : ay.w0) * (uz ? az.w1 : az.w0);
+          t.o[q] = off ? vol * C : (o000 + (ux ? 1 : 0) + (uy ? nx : 0) + (uz ? nx * ny : 0)) * C;
+          t.w[q] = off ? 0.f : w;
+        }
+        taps[tid] = t;
+      }
+      // my points of the chunk: every dX value is requested before the first use
+      float gval[MYP][LIST_N_STENCIL];
+#pragma unroll
+      for (int m = 0; m < MYP; ++m) {
+        const int64_t o = (row0 + r.first + ch + k + COPIES * m) * sp.g.Kp + col_off + c;
+#pragma unroll
+        for (int j = 0; j < LIST_N_STENCIL; ++j) gval[m][j] = dx_at<DXH>(sp.dx, o + j * C);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < MYP; ++m)
+#pragma unroll
+        for (int j = 0; j < LIST_N_STENCIL; ++j) {
+          const TapRec& t = taps[(k + COPIES * m) * LIST_N_STENCIL + j];
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = mine[t.o[q]];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) mine[t.o[q]] = fmaf(t.w[q], gval[m][j], v[q]);
+        }
+    }
+    __syncthreads();
+    float* base = gout + (int64_t)r.b * gv.image_stride;
+    for (int i = tid; i < vol * C; i += T) {
+      const int vox = i / C, cc = i - vox * C;
+      float sum = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < COPIES; ++kk) sum += win[(kk * (vol + 1) + vox) * C + cc];
+      if (sum == 0.f) continue;
+      const int vx = vox % nx, vy = (vox / nx) % ny, vz = vox / (nx * ny);
+      atomicAdd(base + ((int64_t)((r.oz + vz) * H + (r.oy + vy)) * W + (r.ox + vx)) * C + cc, sum * inv_s);
+    }
+    __syncthreads();                                 // the next run re-zeroes the window
+  }
+}
+
+// scalar (C == 1) levels: one lane per (point, stencil point)
+template <int DXH>
+__global__ __launch_bounds__(256) void k_scatter_vox1(ScatterParams sp, ListVoxLevel gv, int col_off) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int row = t >> 3, j = t & 7;
+  if (row >= sp.g.n_valid || j >= LIST_N_STENCIL) return;
+  const Pt p = load_point(sp.g, row);
+  float x, y, z;
+  stencil_rt(p, j, x, y, z);
+  const Taps tp = make_taps(x, y, z, 1, gv.D, gv.H, gv.W);
+  const float gval = dx_at<DXH>(sp.dx, (int64_t)row * sp.g.Kp + col_off + j) * sp.scale[1];
+  float* base = (float*)gv.data + (int64_t)p.b * gv.image_stride;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) atomicAdd(base + tp.o[k], tp.w[k] * gval);
+}
+
+template <int C>
+static hipError_t scatter_level(const ScatterParams& sp, const ListVoxLevel& gv, int col_off, hipStream_t s) {
+  const dim3 grid((unsigned)(sp.g.rows / kScatterRows));
+  const int big = gv.W > gv.H ? (gv.W > gv.D ? gv.W : gv.D) : (gv.H > gv.D ? gv.H : gv.D);
+  const float reach = kDisp * 0.5f * (float)(big - 1);          // stencil displacement in voxels
+  if constexpr (C >= 64) {
+    if (reach < 0.99f) {
+      constexpr int T = C >= 128 ? C : 128;
+      if (sp.dx_f16) hipLaunchKernelGGL((k_scatter_vox_win<C, 1>), grid, dim3(T), 0, s, sp, gv, col_off);
+      else hipLaunchKernelGGL((k_scatter_vox_win<C, 0>), grid, dim3(T), 0, s, sp, gv, col_off);
+      return hipGetLastError();
+    }
+  }
+  if (sp.dx_f16) hipLaunchKernelGGL((k_scatter_vox<C, 1>), grid, dim3(256), 0, s, sp, gv, col_off);
+  else hipLaunchKernelGGL((k_scatter_vox<C, 0>), grid, dim3(256), 0, s, sp, gv, col_off);
+  return hipGetLastError();
+}
+
+hipError_t launch_scatter_vox(const ScatterParams& sp, const FeatLayout& L, const ListQueryArgs& a,
+                              const ListVoxLevel grad_vox[LIST_N_VOX_LEVELS], hipStream_t s) {
+  (void)a;
+  for (int l = 0; l < LIST_N_VOX_LEVELS; ++l) {
+    const ListVoxLevel& gv = grad_vox[l];
+    if (!gv.data) continue;
+    const int B = (int)((sp.g.p_begin + sp.g.n_valid + sp.g.N - 1) / sp.g.N);
+    hipError_t e = hipMemsetAsync((void*)gv.data, 0, (size_t)B * gv.image_stride * sizeof(float), s);
+    if (e != hipSuccess) return e;
+    if (gv.C == 1) {
+      const dim3 grid((unsigned)((sp.g.n_valid * 8 + 255) / 256));
+      if (sp.dx_f16) hipLaunchKernelGGL(k_scatter_vox1<1>, grid, dim3(256), 0, s, sp, gv, L.vox_off[l]);
+      else hipLaunchKernelGGL(k_scatter_vox1<0>, grid, dim3(256), 0, s, sp, gv, L.vox_off[l]);
+      e = hipGetLastError();
+    } else {
+      switch (gv.C) {
+        case 4: e = scatter_level<4>(sp, gv, L.vox_off[l], s); break;
+        case 8: e = scatter_level<8>(sp, gv, L.vox_off[l], s); break;
+        case 16: e = scatter_level<16>(sp, gv, L.vox_off[l], s); break;
+        case 32: e = scatter_level<32>(sp, gv, L.vox_off[l], s); break;
+        case 64: e = scatter_level<64>(sp, gv, L.vox_off[l], s); break;
+        case 128: e = scatter_level<128>(sp, gv, L.vox_off[l], s); break;
+        case 256: e = scatter_level<256>(sp, gv, L.vox_off[l], s); break;
+        default: return hipErrorInvalidValue;
+      }
+    }
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+// ---- perceptual map ------------------------------------------------------------------------------------------
+// Per-point record of the 2-D sample, in pixel order (slot -> point): everything the map gradient
+// needs, so that the per-pixel gather reads 32 B per candidate instead of re-projecting.
+struct ImgRec { int x0, y0; int row; int b; float wx0, wx1, wy0, wy1; };
+static_assert(sizeof(ImgRec) == 32, "ImgRec is 32 bytes");
+
+// the projection of network/modules.py:37-47 with the intermediate values the chain rule needs
+struct ProjFull { float X, Y, den, u_raw, v_raw; int pass_u, pass_v; float ix, iy; int x0, y0; float wx0, wx1, wy0, wy1; };
+
+__device__ __forceinline__ ProjFull project_full(const float* __restrict__ T, float px, float py, float pz,
+                                                 int ms, float clamp_hi) {
+  ProjFull r;
+  float X = px * T[0], Y = px * T[1], Z = px * T[2];
+  X = fmaf(py, T[3], X); Y = fmaf(py, T[4], Y); Z = fmaf(py, T[5], Z);
+  X = fmaf(pz, T[6], X); Y = fmaf(pz, T[7], Y); Z = fmaf(pz, T[8], Z);
+  X = X + T[9]; Y = Y + T[10]; Z = Z + T[11];
+  r.X = X; r.Y = Y; r.den = Z + 1e-8f;
+  r.u_raw = __fdiv_rn(X, r.den); r.v_raw = __fdiv_rn(Y, r.den);
+  r.pass_u = (r.u_raw >= 0.f && r.u_raw <= clamp_hi) ? 1 : 0;     // torch.clamp backward mask
+  r.pass_v = (r.v_raw >= 0.f && r.v_raw <= clamp_hi) ? 1 : 0;
+  const float u = clamp_keep_nan(r.u_raw, clamp_hi), v = clamp_keep_nan(r.v_raw, clamp_hi);
+  const float half = (float)(ms - 1) * 0.5f;
+  const float gx = __fdiv_rn(u - half, half), gy = __fdiv_rn(v - half, half);
+  r.ix = (gx + 1.f) * half; r.iy = (gy + 1.f) * half;
+  const float fx = floorf(r.ix), fy = floorf(r.iy);
+  r.wx1 = r.ix - fx; r.wx0 = (fx + 1.f) - r.ix;
+  r.wy1 = r.iy - fy; r.wy0 = (fy + 1.f) - r.iy;
+  r.x0 = min(max((int)fx, 0), ms - 1); r.y0 = min(max((int)fy, 0), ms - 1);
+  return r;
+}
+
+__device__ __forceinline__ Pt load_point_raw(const GatherParams& g, int pt) {
+  Pt p;
+  p.valid = true;
+  const int64_t gp = g.p_begin + pt;
+  p.b = (int)(gp / g.N);
+  const int n = (int)(gp - (int64_t)p.b * g.N);
+  const float* q = g.query + (int64_t)p.b * g.q_sb + (int64_t)n * g.q_sn;
+  p.x = q[(int64_t)g.perm0 * g.q_sc] * g.scale;
+  p.y = q[(int64_t)g.perm1 * g.q_sc] * g.scale;
+  p.z = q[(int64_t)g.perm2 * g.q_sc] * g.scale;
+  return p;
+}
+
+// slot -> (point, X row): pixel order when the forward built one, else row order
+__device__ __forceinline__ void slot_point(const GatherParams& g, int slot, int& pt, int& row) {
+  if (g.order_img) { pt = g.order_img[slot]; row = g.row_of[pt]; }
+  else { row = slot; pt = g.order ? g.order[slot] : slot; }
+}
+
+__global__ __launch_bounds__(256) void k_img_records(GatherParams g, const float* __restrict__ trans_mat, int ms,
+                                                     float clamp_hi, ImgRec* __restrict__ recs) {
+  const int slot = blockIdx.x * 256 + threadIdx.x;
+  if (slot >= g.n_valid) return;
+  int pt, row;
+  slot_point(g, slot, pt, row);
+  const Pt p = load_point_raw(g, pt);
+  const ProjFull pr = project_full(trans_mat + p.b * 12, p.x, p.y, p.z, ms, clamp_hi);
+  ImgRec r;
+  r.x0 = pr.x0; r.y0 = pr.y0; r.row = row; r.b = p.b;
+  r.wx0 = pr.wx0; r.wx1 = pr.wx1; r.wy0 = pr.wy0; r.wy1 = pr.wy1;
+  recs[slot] = r;
+}
+
+// One workgroup per (image, map row Y, group of 4 map columns); thread t owns channels 4t .. 4t+3 (and
+// +1024 ...).  Candidates = the points of the <= 4 pixel cells (rows Y-1, Y; column groups cx-1, cx)
+// whose 2x2 footprint can reach the group; each contributes w(tap) * dX[row][img_off + c].
+constexpr int kImgCand = 128;
+
+template <int DXH>
+__global__ __launch_bounds__(256) void k_img_grad_gather(ScatterParams sp, const ImgRec* __restrict__ recs,
+                                                         const int* __restrict__ bins, int b_first, int ms,
+                                                         int Ct, int img_off, float* __restrict__ out) {
+  __shared__ ImgRec cand[kImgCand];
+  const int cw = (ms + 3) / 4;
+  const int cx = blockIdx.x % cw;
+  const int Y = (blockIdx.x / cw) % ms;
+  const int b = blockIdx.x / (cw * ms);
+  const int slot_img = (b - b_first) % kSortImages;
+  const int X0 = 4 * cx;
+  const float inv_s = sp.scale[1];
+  const int nq = Ct / 4;                                   // channel quads
+
+  // candidate slot ranges of the 4 cells (bins hold END offsets after the forward's scatter pass)
+  int beg[4], end[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int yy = Y - 1 + (k >> 1), cc = cx - 1 + (k & 1);
+    beg[k] = end[k] = 0;
+    if (yy < 0 || cc < 0) continue;
+    const int bin = slot_img * kSortPixCells + min(yy * cw + cc, kSortPixCells - 1);
+    beg[k] = bin > 0 ? bins[bin - 1] : 0;
+    end[k] = bins[bin];
+  }
+  float acc[4][4];
+  for (int q0 = 0; q0 < nq; q0 += 256) {
+    const int qd = q0 + threadIdx.x;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
+    for (int k = 0; k < 4; ++k) {
+      for (int s0 = beg[k]; s0 < end[k]; s0 += kImgCand) {
+        const int n = min(kImgCand, end[k] - s0);
+        __syncthreads();
+        if ((int)threadIdx.x < n) cand[threadIdx.x] = recs[s0 + threadIdx.x];
+        __syncthreads();
+        for (int i = 0; i < n; ++i) {
+          const ImgRec r = cand[i];
+          if (r.b != b) continue;                            // a clamped bin index may mix images: never, but cheap
+          const float wy = (r.y0 == Y) ? r.wy0 : ((r.y0 + 1 == Y) ? r.wy1 : 0.f);
+          if ((r.y0 != Y && r.y0 + 1 != Y) || r.x0 + 1 < X0 || r.x0 > X0 + 3) continue;
+          if (qd >= nq) continue;
+          float gv[4];
+          const int64_t o = (int64_t)r.row * sp.g.Kp + img_off + qd * 4;
+          if (DXH) {
+            const uint2 h = *(const uint2*)((const unsigned short*)sp.dx + o);
+            gv[0] = h2f((unsigned short)(h.x & 0xffff)); gv[1] = h2f((unsigned short)(h.x >> 16));
+            gv[2] = h2f((unsigned short)(h.y & 0xffff)); gv[3] = h2f((unsigned short)(h.y >> 16));
+          } else {
+            const float4 f = *(const float4*)((const float*)sp.dx + o);
+            gv[0] = f.x; gv[1] = f.y; gv[2] = f.z; gv[3] = f.w;
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int X = X0 + t;
+            const float wx = (r.x0 == X) ? r.wx0 : ((r.x0 + 1 == X) ? r.wx1 : 0.f);
+            const float w = wx * wy;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][e] = fmaf(w, gv[e], acc[t][e]);
+          }
+        }
+      }
+    }
+    if (qd < nq) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int X = X0 + t;
+        if (X >= ms) continue;
+        float4 v = make_float4(acc[t][0] * inv_s, acc[t][1] * inv_s, acc[t][2] * inv_s, acc[t][3] * inv_s);
+        *(float4*)(out + ((int64_t)(b * ms + Y) * ms + X) * Ct + qd * 4) = v;
+      }
+    }
+  }
+}
+
+// Fallback without a pixel order (maps wider than the sort's bins, or no_sort): atomics, lanes over channels.
+template <int DXH>
+__global__ __launch_bounds__(256) void k_img_grad_atomic(ScatterParams sp, const ImgRec* __restrict__ recs, int ms,
+                                                         int Ct, int img_off, float* __restrict__ out) {
+  const int slot0 = blockIdx.x * kGatherRows;
+  const float inv_s = sp.scale[1];
+  for (int i = 0; i < kGatherRows; ++i) {
+    const int slot = slot0 + i;
+    if (slot >= sp.g.n_valid) return;
+    const ImgRec r = recs[slot];
+    const int x1 = min(r.x0 + 1, ms - 1), y1 = min(r.y0 + 1, ms - 1);
+    float* base = out + (int64_t)r.b * ms * ms * Ct;
+    float* p00 = base + (int64_t)(r.y0 * ms + r.x0) * Ct; float* p01 = base + (int64_t)(r.y0 * ms + x1) * Ct;
+    float* p10 = base + (int64_t)(y1 * ms + r.x0) * Ct;   float* p11 = base + (int64_t)(y1 * ms + x1) * Ct;
+    for (int c = threadIdx.x; c < Ct; c += 256) {
+      const float gval = dx_at<DXH>(sp.dx, (int64_t)r.row * sp.g.Kp + img_off + c) * inv_s;
+      atomicAdd(p00 + c, r.wx0 * r.wy0 * gval); atomicAdd(p01 + c, r.wx1 * r.wy0 * gval);
+      atomicAdd(p10 + c, r.wx0 * r.wy1 * gval); atomicAdd(p11 + c, r.wx1 * r.wy1 * gval);
+    }
+  }
+}
+
+// ---- trans_mat ------------------------------------------------------------------------------------------------
+// d(feature_c)/d(ix) = wy0 (m01 - m00) + wy1 (m11 - m10), d/d(iy) = wx0 (m10 - m00) + wx1 (m11 - m01)
+// (grid_sampler_2d_backward; a tap outside the map counts as zero); then ix = (gx+1)*half, gx = (u-half)/half,
+// u = clamp(X/den), den = Z + 1e-8, [X Y Z] = [p 1] . T.
+template <int F16>
+__device__ __forceinline__ float map_at(const void* __restrict__ m, int64_t i) {
+  return F16 ? h2f(((const unsigned short*)m)[i]) : ((const float*)m)[i];
+}
+
+// 8 consecutive channels of a map tap / of dX as floats (one or two 16-B loads)
+template <int F16>
+__device__ __forceinline__ void load8(const void* __restrict__ base, int64_t i, float (&f)[8]) {
+  if (F16) {
+    const uint4 r = *(const uint4*)((const unsigned short*)base + i);
+    f[0] = h2f((unsigned short)(r.x & 0xffff)); f[1] = h2f((unsigned short)(r.x >> 16));
+    f[2] = h2f((unsigned short)(r.y & 0xffff)); f[3] = h2f((unsigned short)(r.y >> 16));
+    f[4] = h2f((unsigned short)(r.z & 0xffff)); f[5] = h2f((unsigned short)(r.z >> 16));
+    f[6] = h2f((unsigned short)(r.w & 0xffff)); f[7] = h2f((unsigned short)(r.w >> 16));
+  } else {
+    const float4 a = *(const float4*)((const float*)base + i), b = *(const float4*)((const float*)base + i + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+  }
+}
+
+struct TransPt { int64_t o00; int sx, sy; int row, b, valid; float wx0, wx1, wy0, wy1; float X, Y, den; int pass_u, pass_v;
+                 float px, py, pz; };
+
+// grid = rows/64, block = 256: the first 64 threads project the workgroup's points (pixel order), then
+// the workgroup walks them with lanes over channel octets (16-B loads of the four taps and of dX), a
+// whole number of points per pass; wave shuffles + LDS reduce the two coordinate derivatives per point.
+template <int F16, int DXH>
+__global__ __launch_bounds__(256) void k_trans_grad(ScatterParams sp, const void* __restrict__ img_map,
+                                                    const float* __restrict__ trans_mat, int ms, int Ct,
+                                                    float clamp_hi, int img_off, float* __restrict__ grad_T) {
+  __shared__ TransPt tp[kGatherRows];
+  __shared__ float s_gx[kGatherRows][4], s_gy[kGatherRows][4];
+  const int blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t img_stride = (int64_t)ms * ms * Ct;
+  if (threadIdx.x < kGatherRows) {
+    TransPt t;
+    const int slot = blk * kGatherRows + threadIdx.x;
+    t.valid = slot < sp.g.n_valid ? 1 : 0;
+    int pt = 0, row = 0;
+    if (t.valid) slot_point(sp.g, slot, pt, row);
+    const Pt p = load_point_raw(sp.g, pt);
+    const ProjFull pr = project_full(trans_mat + p.b * 12, p.x, p.y, p.z, ms, clamp_hi);
+    t.o00 = p.b * img_stride + (int64_t)(pr.y0 * ms + pr.x0) * Ct;
+    t.sx = pr.x0 + 1 < ms ? Ct : -1;                       // -1: the tap lies outside the map (counts as zero)
+    t.sy = pr.y0 + 1 < ms ? ms * Ct : -1;
+    t.row = row; t.b = p.b;
+    t.wx0 = pr.wx0; t.wx1 = pr.wx1; t.wy0 = pr.wy0; t.wy1 = pr.wy1;
+    t.X = pr.X; t.Y = pr.Y; t.den = pr.den; t.pass_u = pr.pass_u; t.pass_v = pr.pass_v;
+    t.px = p.x; t.py = p.y; t.pz = p.z;
+    tp[threadIdx.x] = t;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { s_gx[threadIdx.x][w] = 0.f; s_gy[threadIdx.x][w] = 0.f; }
+  }
+  __syncthreads();
+  const int lq = Ct / 8;                                   // lanes that cover one point
+  if (Ct % 8 == 0 && img_off % 8 == 0 && lq >= 4 && lq <= 256 && 256 % lq == 0) {
+    const int ppp = 256 / lq;                              // points per pass
+    const int pp = threadIdx.x / lq, q = threadIdx.x - pp * lq;
+    for (int i = 0; i < kGatherRows; i += ppp) {
+      const TransPt& t = tp[i + pp];
+      float gx = 0.f, gy = 0.f;
+      if (t.valid) {
+        float g[8], m00[8], m01[8], m10[8], m11[8];
+        load8<DXH>(sp.dx, (int64_t)t.row * sp.g.Kp + img_off + q * 8, g);
+        const int64_t o = t.o00 + q * 8;
+        load8<F16>(img_map, o, m00);
+        load8<F16>(img_map, o + (t.sx > 0 ? t.sx : 0), m01);
+        load8<F16>(img_map, o + (t.sy > 0 ? t.sy : 0), m10);
+        load8<F16>(img_map, o + (t.sx > 0 ? t.sx : 0) + (t.sy > 0 ? t.sy : 0), m11);
+        const float kx = t.sx > 0 ? 1.f : 0.f, ky = t.sy > 0 ? 1.f : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float a01 = m01[e] * kx, a10 = m10[e] * ky, a11 = m11[e] * kx * ky;
+          gx = fmaf(g[e], t.wy0 * (a01 - m00[e]) + t.wy1 * (a11 - a10), gx);
+          gy = fmaf(g[e], t.wx0 * (a10 - m00[e]) + t.wx1 * (a11 - a01), gy);
+        }
+      }
+      // lanes of one point sit in whole waves (lq >= 64) or in aligned sub-wave groups (lq < 64)
+      const int width = lq < 64 ? lq : 64;
+      for (int off = width >> 1; off > 0; off >>= 1) { gx += __shfl_xor(gx, off); gy += __shfl_xor(gy, off); }
+      if ((lane & (width - 1)) == 0) {
+        if (lq >= 64) { s_gx[i + pp][wave % (lq / 64)] = gx; s_gy[i + pp][wave % (lq / 64)] = gy; }
+        else { s_gx[i + pp][0] = gx; s_gy[i + pp][0] = gy; }
+      }
+    }
+  } else {
+    // unusual channel counts: one wave per point, scalar channels
+    for (int i = wave; i < kGatherRows; i += 4) {
+      const TransPt& t = tp[i];
+      float gx = 0.f, gy = 0.f;
+      if (t.valid)
+        for (int c = lane; c < Ct; c += 64) {
+          const float g = dx_at<DXH>(sp.dx, (int64_t)t.row * sp.g.Kp + img_off + c);
+          const float m00 = map_at<F16>(img_map, t.o00 + c);
+          const float m01 = t.sx > 0 ? map_at<F16>(img_map, t.o00 + t.sx + c) : 0.f;
+          const float m10 = t.sy > 0 ? map_at<F16>(img_map, t.o00 + t.sy + c) : 0.f;
+          const float m11 = (t.sx > 0 && t.sy > 0) ? map_at<F16>(img_map, t.o00 + t.sx + t.sy + c) : 0.f;
+          gx = fmaf(g, t.wy0 * (m01 - m00) + t.wy1 * (m11 - m10), gx);
+          gy = fmaf(g, t.wx0 * (m10 - m00) + t.wx1 * (m11 - m01), gy);
+        }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) { gx += __shfl_xor(gx, off); gy += __shfl_xor(gy, off); }
+      if (lane == 0) { s_gx[i][0] = gx; s_gy[i][0] = gy; }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x >= kGatherRows) return;
+  // chain rule per point, then one reduction per image present in the workgroup
+  float d[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) d[k] = 0.f;
+  const TransPt t = tp[threadIdx.x];
+  const int b = t.valid ? t.b : -1;
+  if (t.valid) {
+    const float gix = (s_gx[threadIdx.x][0] + s_gx[threadIdx.x][1]) + (s_gx[threadIdx.x][2] + s_gx[threadIdx.x][3]);
+    const float giy = (s_gy[threadIdx.x][0] + s_gy[threadIdx.x][1]) + (s_gy[threadIdx.x][2] + s_gy[threadIdx.x][3]);
+    const float half = (float)(ms - 1) * 0.5f;
+    const float inv_s = sp.scale[1];
+    // d/d(gx) = half * d/d(ix)  (grid_sampler unnormalize);  d/du = (1/half) * d/d(gx)
+    const float du = t.pass_u ? __fdiv_rn(gix * half, half) * inv_s : 0.f;
+    const float dv = t.pass_v ? __fdiv_rn(giy * half, half) * inv_s : 0.f;
+    if (du != 0.f || dv != 0.f) {           // (clamped projections contribute exactly nothing, also when den == 0)
+      const float dX = __fdiv_rn(du, t.den), dY = __fdiv_rn(dv, t.den);
+      const float dZ = -(__fdiv_rn(du * t.X, t.den * t.den) + __fdiv_rn(dv * t.Y, t.den * t.den));
+      const float h[4] = {t.px, t.py, t.pz, 1.f};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { d[3 * k] = h[k] * dX; d[3 * k + 1] = h[k] * dY; d[3 * k + 2] = h[k] * dZ; }
+    }
+  }
+  // threads 0..63 are wave 0: reduce per image with shuffles
+  int bmin = b < 0 ? INT_MAX : b, bmax = b;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    bmin = min(bmin, __shfl_xor(bmin, off));
+    bmax = max(bmax, __shfl_xor(bmax, off));
+  }
+  for (int bi = bmin; bi <= bmax && bmax >= 0; ++bi) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      float v = (b == bi) ? d[k] : 0.f;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+      if (threadIdx.x == 0 && v != 0.f) atomicAdd(grad_T + bi * 12 + k, v);
+    }
+  }
+}
+
+hipError_t launch_img_grad(const ScatterParams& sp, const FeatLayout& L, const ListQueryArgs& a,
+                           const int* bins_pix, int nslots, void* recs, float* grad_img_map,
+                           float* grad_trans_mat, void* const* stage_events, hipStream_t s) {
+  (void)nslots;
+  const int ms = a.map_size, Ct = L.img_C;
+  ImgRec* rc = (ImgRec*)recs;
+  auto mark = [&](int stage) {
+    if (stage_events && stage_events[stage]) (void)hipEventRecord((hipEvent_t)stage_events[stage], s);
+  };
+  if (grad_img_map) {
+    hipLaunchKernelGGL(k_img_records, dim3((unsigned)((sp.g.n_valid + 255) / 256)), dim3(256), 0, s, sp.g,
+                       a.trans_mat, ms, a.clamp_hi, rc);
+    const int B = (int)((sp.g.p_begin + sp.g.n_valid + sp.g.N - 1) / sp.g.N);
+    if (sp.g.order_img && bins_pix) {
+      const dim3 grid((unsigned)(B * ms * ((ms + 3) / 4)));
+      if (sp.dx_f16)
+        hipLaunchKernelGGL(k_img_grad_gather<1>, grid, dim3(256), 0, s, sp, rc, bins_pix, (int)(sp.g.p_begin / sp.g.N),
+                           ms, Ct, L.img_off, grad_img_map);
+      else
+        hipLaunchKernelGGL(k_img_grad_gather<0>, grid, dim3(256), 0, s, sp, rc, bins_pix, (int)(sp.g.p_begin / sp.g.N),
+                           ms, Ct, L.img_off, grad_img_map);
+    } else {
+      hipError_t e = hipMemsetAsync(grad_img_map, 0, (size_t)B * ms * ms * Ct * sizeof(float), s);
+      if (e != hipSuccess) return e;
+      const dim3 grid((unsigned)((sp.g.n_valid + kGatherRows - 1) / kGatherRows));
+      if (sp.dx_f16)
+        hipLaunchKernelGGL(k_img_grad_atomic<1>, grid, dim3(256), 0, s, sp, rc, ms, Ct, L.img_off, grad_img_map);
+      else
+        hipLaunchKernelGGL(k_img_grad_atomic<0>, grid, dim3(256), 0, s, sp, rc, ms, Ct, L.img_off, grad_img_map);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  mark(LIST_BWD_IMG);
+  if (grad_trans_mat) {
+    const int B = (int)((sp.g.p_begin + sp.g.n_valid + sp.g.N - 1) / sp.g.N);
+    hipError_t e = hipMemsetAsync(grad_trans_mat, 0, (size_t)B * 12 * sizeof(float), s);
+    if (e != hipSuccess) return e;
+    const dim3 grid((unsigned)(sp.g.rows / kGatherRows));
+    const int f16 = a.img_dtype == LIST_MAP_F16;
+    if (f16 && sp.dx_f16)
+      hipLaunchKernelGGL((k_trans_grad<1, 1>), grid, dim3(256), 0, s, sp, a.img_map, a.trans_mat, ms, Ct, a.clamp_hi,
+                         L.img_off, grad_trans_mat);
+    else if (f16)
+      hipLaunchKernelGGL((k_trans_grad<1, 0>), grid, dim3(256), 0, s, sp, a.img_map, a.trans_mat, ms, Ct, a.clamp_hi,
+                         L.img_off, grad_trans_mat);
+    else if (sp.dx_f16)
+      hipLaunchKernelGGL((k_trans_grad<0, 1>), grid, dim3(256), 0, s, sp, a.img_map, a.trans_mat, ms, Ct, a.clamp_hi,
+                         L.img_off, grad_trans_mat);
+    else
+      hipLaunchKernelGGL((k_trans_grad<0, 0>), grid, dim3(256), 0, s, sp, a.img_map, a.trans_mat, ms, Ct, a.clamp_hi,
+                         L.img_off, grad_trans_mat);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  mark(LIST_BWD_TRANS);
+  return hipSuccess;
+}
+
+// ---- adjoint of the resize (list_prep_img_maps) ----------------------------------------------------------
+// out[b][c][ys][xs] = sum over map pixels (oy, ox) whose bilinear footprint contains (ys, xs) of
+// wy * wx * G[b][oy][ox][coff + c], with the forward's own index/weight arithmetic (prep_kernels.hip).
+// One workgroup per (image, source row ys, 64 channels), separable:
+//   1. R[ox][c] = sum_oy wy(oy, ys) G[b][oy][ox][c]   threads = (4 channels, 16 x lanes), 16-B loads that
+//      run 256 B along the channels; every thread keeps its <= 20 columns in registers;
+//   2. out[c][xs] = sum_ox wx(ox, xs) R[ox][c]          R through LDS, per-xs tap lists in CSR form;
+//   3. the [64][W] tile turns through LDS so the NCHW writes run along x.
+constexpr int kAdjMaxMs = 320;             // largest supported map_size
+constexpr int kAdjXl = 16;                 // x lanes of phase 1
+constexpr int kAdjCols = kAdjMaxMs / kAdjXl;
+
+// the forward's footprint of map index o on a source axis of S pixels
+__device__ __forceinline__ void adj_footprint(int o, int S, int ms, int& i0, int& i1, float& w0, float& w1) {
+  const float sc = ms > 1 ? (float)(S - 1) / (float)(ms - 1) : 0.f;
+  const float f = sc * (float)o;
+  i0 = min((int)f, S - 1);
+  i1 = i0 + (i0 < S - 1 ? 1 : 0);
+  w1 = f - (float)i0;
+  w0 = 1.f - w1;
+}
+
+__global__ __launch_bounds__(256) void k_img_grad_level(const float* __restrict__ G, int ms, int Ct, int coff,
+                                                        ListMap2D m) {
+  extern __shared__ __attribute__((aligned(16))) float dyn[];
+  // dynamic LDS: R[ms][64] | tile[64][W + 1] | csr_w[2 ms] | csr_ox[2 ms] | csr_beg[W + 1] | oy list
+  float* R = dyn;
+  float* tile = R + ms * 64;
+  float* csr_w = tile + 64 * (m.W + 1);
+  int* csr_ox = (int*)(csr_w + 2 * ms);
+  int* csr_beg = csr_ox + 2 * ms;
+  int* s_oy = csr_beg + (m.W + 1);
+  float* s_wy = (float*)(s_oy + ms);
+  __shared__ int s_ny;
+  const int ys = blockIdx.x % m.H;
+  const int b = blockIdx.x / m.H;
+  const int c0 = blockIdx.y * 64;
+  if (threadIdx.x == 0) {
+    // rows of the map that touch source row ys (ascending oy), and the CSR of the x axis
+    int n = 0;
+    for (int o = 0; o < ms; ++o) {
+      int i0, i1; float w0, w1;
+      adj_footprint(o, m.H, ms, i0, i1, w0, w1);
+      if (i0 == ys || i1 == ys) { s_oy[n] = o; s_wy[n] = (i0 == ys ? w0 : 0.f) + (i1 == ys ? w1 : 0.f); ++n; }
+    }
+    s_ny = n;
+  }
+  if (threadIdx.x == 64) {
+    // footprints are monotone in ox: xs collects a contiguous range of ox
+    int e = 0, o_lo = 0;
+    for (int xs = 0; xs < m.W; ++xs) {
+      csr_beg[xs] = e;
+      for (int o = o_lo; o < ms; ++o) {
+        int i0, i1; float w0, w1;
+        adj_footprint(o, m.W, ms, i0, i1, w0, w1);
+        if (i0 > xs) break;
+        if (i1 < xs) { o_lo = o + 1; continue; }
+        csr_ox[e] = o; csr_w[e] = (i0 == xs ? w0 : 0.f) + (i1 == xs ? w1 : 0.f); ++e;
+      }
+    }
+    csr_beg[m.W] = e;
+  }
+  __syncthreads();
+  // ---- phase 1
+  const int cq = threadIdx.x & 15, xl = threadIdx.x >> 4;
+  const int nc4 = min(64, m.C - c0) / 4;               // channel quads that exist (C % 4 == 0)
+  float4 acc[kAdjCols];
+#pragma unroll
+  for (int k = 0; k < kAdjCols; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (cq < nc4) {
+    const int ny = s_ny;
+    for (int iy = 0; iy < ny; ++iy) {
+      const float wy = s_wy[iy];
+      const float* Gr = G + ((int64_t)(b * ms + s_oy[iy]) * ms) * Ct + coff + c0 + cq * 4;
+#pragma unroll
+      for (int k = 0; k < kAdjCols; ++k) {
+        const int ox = xl + kAdjXl * k;
+        if (ox < ms) {
+          const float4 v = *(const float4*)(Gr + (int64_t)ox * Ct);
+          acc[k].x = fmaf(wy, v.x, acc[k].x); acc[k].y = fmaf(wy, v.y, acc[k].y);
+          acc[k].z = fmaf(wy, v.z, acc[k].z); acc[k].w = fmaf(wy, v.w, acc[k].w);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kAdjCols; ++k) {
+    const int ox = xl + kAdjXl * k;
+    if (ox < ms) *(float4*)(R + ox * 64 + cq * 4) = acc[k];
+  }
+  __syncthreads();
+  // ---- phase 2
+  const int c = threadIdx.x & 63, xq = threadIdx.x >> 6;
+  for (int xs = xq; xs < m.W; xs += 4) {
+    float a = 0.f;
+    for (int e = csr_beg[xs]; e < csr_beg[xs + 1]; ++e) a = fmaf(csr_w[e], R[csr_ox[e] * 64 + c], a);
+    tile[c * (m.W + 1) + xs] = a;
+  }
+  __syncthreads();
+  // ---- phase 3
+  float* out = const_cast<float*>(m.data) + (int64_t)b * m.sb + (int64_t)ys * m.sh;
+  for (int i = threadIdx.x; i < 64 * m.W; i += 256) {
+    const int cc = i / m.W, xs = i - cc * m.W;
+    if (c0 + cc < m.C) out[(int64_t)(c0 + cc) * m.sc + (int64_t)xs * m.sw] = tile[cc * (m.W + 1) + xs];
+  }
+}
+
+hipError_t launch_img_grad_to_levels(const float* grad_img_map, int B, int map_size, int Ct,
+                                     const ListMap2D grads[LIST_N_IMG_LEVELS], hipStream_t s) {
+  if (map_size > kAdjMaxMs) return hipErrorInvalidValue;
+  int coff = 0;
+  for (int i = 0; i < LIST_N_IMG_LEVELS; ++i) {
+    const ListMap2D& m = grads[i];
+    if (m.data) {
+      if (m.C % 4 || coff % 4 || Ct % 4) return hipErrorInvalidValue;
+      const size_t lds = sizeof(float) * ((size_t)map_size * 64 + 64 * (size_t)(m.W + 1) + 2 * (size_t)map_size) +
+                         sizeof(int) * (2 * (size_t)map_size + (size_t)(m.W + 1) + (size_t)map_size) +
+                         sizeof(float) * (size_t)map_size;
+      if (lds > 150 * 1024) return hipErrorInvalidValue;
+      if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_img_grad_level, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) return e;
+      }
+      const dim3 grid((unsigned)(B * m.H), (unsigned)((m.C + 63) / 64));
+      hipLaunchKernelGGL(k_img_grad_level, grid, dim3(256), lds, s, grad_img_map, map_size, Ct, coff, m);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return e;
+    }
+    coff += m.C;
+  }
+  return hipSuccess;
+}
+
+}  // namespace list

@@ -188,7 +188,40 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(GemmParams p) {
 
   // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const int col_in = lane & 31, row_in = 4 * (lane >> 5);
-  if (EPI == EPI_RELU_SPLIT || EPI == EPI_F32) {
+  if (EPI == EPI_MASK_SPLIT) {
+    // ReLU backward: dZ_prev = acc where the saved activation is positive (network/modules.py:276-278)
+    const int64_t lane_off = (int64_t)(m0 + wm * 128 + row_in) * p.ldo + n0 + wn * 64 + col_in;
+    const int64_t mask_off = (int64_t)(m0 + wm * 128 + row_in) * p.ldmask + n0 + wn * 64 + col_in;
+    unsigned short* oh = p.out_hi + lane_off;
+    unsigned short* ol = p.out_lo ? p.out_lo + lane_off : nullptr;
+    const unsigned short* mk = p.mask + mask_off;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int r = i * 32 + (e & 3) + 8 * (e >> 2);
+          const float v = (mk[r * p.ldmask + j * 32] & 0x7fff) ? acc[i][j][e] : 0.f;
+          const unsigned short h = to_half_plane<FP16>(v);
+          oh[r * p.ldo + j * 32] = h;
+          if (!FP16 && ol) ol[r * p.ldo + j * 32] = f2bf(v - bf2f(h));
+        }
+  } else if (EPI == EPI_DX) {
+    const int64_t lane_off = (int64_t)(m0 + wm * 128 + row_in) * p.ldo + n0 + wn * 64 + col_in;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (n0 + wn * 64 + j * 32 + col_in >= p.n_store) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int64_t off = lane_off + (int64_t)(i * 32 + (e & 3) + 8 * (e >> 2)) * p.ldo + j * 32;
+          if (p.dx_f16) ((unsigned short*)p.dx)[off] = f2h(acc[i][j][e]);
+          else ((float*)p.dx)[off] = acc[i][j][e];
+        }
+    }
+  } else if (EPI == EPI_RELU_SPLIT || EPI == EPI_F32) {
     // one base pointer per output plane; per-element offsets are (wave-uniform row term) + lane term
     const int ld = EPI == EPI_F32 ? p.N : p.ldo;
     const int64_t lane_off = (int64_t)(m0 + wm * 128 + row_in) * ld + n0 + wn * 64 + col_in;
@@ -429,7 +462,7 @@ static hipError_t launch_one(const GemmParams& p, hipStream_t s) {
   // measured (fp16, P = 160k): the two shapes tie on fc_0 (0.58 ms, the kernel is bound by the LDS-DMA
   // path, not by the MFMA clock); 32x32 has the cheaper 64-B store runs (fc_1 0.074 vs 0.086 ms), 16x16
   // the cheaper row reduction of the fused fc_2 + fc_out epilogue (0.045 vs 0.058 ms)
-  if (EPI == EPI_RELU_DOT)
+  if constexpr (EPI == EPI_RELU_DOT)
     hipLaunchKernelGGL((k_gemm_nt16<TERMS, EPI, FP16>), dim3(ntiles), dim3(512), 0, s, p);
   else
     hipLaunchKernelGGL((k_gemm_nt<TERMS, EPI, FP16>), dim3(ntiles), dim3(512), 0, s, p);
@@ -440,6 +473,8 @@ template <int TERMS, int FP16>
 static hipError_t launch_epi(const GemmParams& p, int epi, hipStream_t s) {
   if (epi == EPI_RELU_SPLIT) return launch_one<TERMS, EPI_RELU_SPLIT, FP16>(p, s);
   if (epi == EPI_F32) return launch_one<TERMS, EPI_F32, FP16>(p, s);
+  if (epi == EPI_MASK_SPLIT) return launch_one<TERMS, EPI_MASK_SPLIT, FP16>(p, s);
+  if (epi == EPI_DX) return launch_one<TERMS, EPI_DX, FP16>(p, s);
   return launch_one<TERMS, EPI_RELU_DOT, FP16>(p, s);
 }
 

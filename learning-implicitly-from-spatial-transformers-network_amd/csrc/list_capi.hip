@@ -374,6 +374,254 @@ int list_percep_pool_fwd(const ListPoolArgs* a, void* stream) {
   return LIST_OK;
 }
 
+// ------------------------------------------------------------------------------------------ backward
+size_t list_packed_mlp_bwd_bytes(const ListMlpWeights* w) {
+  FeatLayout L;
+  if (weights_layout(w, &L) != LIST_OK) return 0;
+  return packed_mlp_bwd_layout(L.Kp, w->H1, w->H2, w->H3).total;
+}
+
+int list_prep_mlp_weights_bwd(const ListMlpWeights* w, void* packed, size_t packed_bytes, void* stream) {
+  FeatLayout L;
+  int rc = weights_layout(w, &L);
+  if (rc != LIST_OK) return rc;
+  const PackedMlpBwd P = packed_mlp_bwd_layout(L.Kp, w->H1, w->H2, w->H3);
+  if (!packed || packed_bytes < P.total)
+    return fail(LIST_ERR_WORKSPACE, "packed_bwd buffer too small: %zu < %zu", packed_bytes, P.total);
+  if (!aligned16(packed)) return fail(LIST_ERR_SHAPE, "packed_bwd must be 16-byte aligned");
+  hipError_t e = launch_prep_weights_bwd(*w, L, P, (char*)packed, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "prep_weights_bwd launch");
+  return LIST_OK;
+}
+
+size_t list_query_bwd_workspace_bytes(int64_t n_points, int32_t F, int32_t H1, int32_t H2, int32_t H3,
+                                      int32_t precision) {
+  if (n_points <= 0 || n_points > kMaxChunkRows || F <= 0 || H1 <= 0 || H2 <= 0 || H3 <= 0) return 0;
+  const int Kp = (F + kKTile - 1) / kKTile * kKTile;
+  const int64_t rows = (n_points + kRowTile - 1) / kRowTile * kRowTile;
+  return bwd_workspace_layout(rows, Kp, H1, H2, H3, precision == LIST_PREC_FP16).total;
+}
+
+int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
+  if (!ga || !ga->fwd) return fail(LIST_ERR_ARG, "args/fwd is NULL");
+  const ListQueryArgs* a = ga->fwd;
+  FeatLayout L;
+  if (a->B >= 0 && a->N >= 0 && (int64_t)a->B * a->N == 0) return LIST_OK;
+  int rc = check_query_common(a, &L);
+  if (rc != LIST_OK) return rc;
+  if (a->percep_feat) return fail(LIST_ERR_UNSUPPORTED, "backward needs the fused form (percep_feat == NULL)");
+  if (!ga->grad_sdf || !ga->packed_mlp_bwd || !a->packed_mlp || !ga->workspace)
+    return fail(LIST_ERR_ARG, "grad_sdf/packed_mlp_bwd/packed_mlp/workspace is NULL");
+  if (a->F != L.F) return fail(LIST_ERR_SHAPE, "F=%d but channels give %d", a->F, L.F);
+  if (a->H1 % 256 || a->H2 % 256 || a->H3 != 256 || a->H1 <= 0 || a->H2 <= 0)
+    return fail(LIST_ERR_UNSUPPORTED, "hidden sizes %d/%d/%d", a->H1, a->H2, a->H3);
+  if (a->H1 > 2048 || a->H2 > 2048)
+    return fail(LIST_ERR_UNSUPPORTED, "backward supports hidden sizes up to 2048 (got %d/%d)", a->H1, a->H2);
+  if (a->precision < LIST_PREC_BF16X3 || a->precision > LIST_PREC_FP16)
+    return fail(LIST_ERR_ARG, "precision=%d", a->precision);
+  const int64_t P = (int64_t)a->B * a->N;
+  if (P > kMaxChunkRows)
+    return fail(LIST_ERR_UNSUPPORTED, "backward handles up to %lld points per call (got %lld)",
+                (long long)kMaxChunkRows, (long long)P);
+  const int64_t rows = chunk_rows_for(a->workspace_bytes, P, L.Kp, a->H1, a->H2);
+  if (rows < P)
+    return fail(LIST_ERR_WORKSPACE, "forward workspace does not hold the whole query in one chunk");
+  const bool fp16 = a->precision == LIST_PREC_FP16;
+  const Workspace ws = workspace_layout(rows, L.Kp, a->H1, a->H2);
+  const BwdWorkspace bw = bwd_workspace_layout(rows, L.Kp, a->H1, a->H2, a->H3, fp16);
+  if (ga->workspace_bytes < bw.total)
+    return fail(LIST_ERR_WORKSPACE, "backward workspace too small: %zu < %zu", ga->workspace_bytes, bw.total);
+  if (!aligned16(ga->workspace)) return fail(LIST_ERR_SHAPE, "workspace must be 16-byte aligned");
+  for (int l = 0; l < LIST_N_VOX_LEVELS; ++l) {
+    const ListVoxLevel& gv = ga->grad_vox[l];
+    if (!gv.data) continue;
+    const ListVoxLevel& v = a->vox[l];
+    if (gv.C != v.C || gv.D != v.D || gv.H != v.H || gv.W != v.W || gv.dtype != LIST_MAP_F32 ||
+        gv.image_stride != (int64_t)v.C * v.D * v.H * v.W)
+      return fail(LIST_ERR_SHAPE, "grad_vox[%d] must be fp32 [B][D][H][W][C] of the level's shape", l);
+  }
+  const PackedMlp pk = packed_mlp_layout(L.Kp, a->H1, a->H2, a->H3);
+  const PackedMlpBwd pb = packed_mlp_bwd_layout(L.Kp, a->H1, a->H2, a->H3);
+  const char* wp = (const char*)a->packed_mlp;
+  const char* wt = (const char*)ga->packed_mlp_bwd;
+  char* fw = (char*)a->workspace;
+  char* bwp = (char*)ga->workspace;
+  const int terms = a->precision == LIST_PREC_BF16X3 ? 3 : 1;
+  const int fmt = fp16 ? FMT_FP16 : FMT_BF16_SPLIT;
+  const bool lo = terms == 3;
+  const int n_valid = (int)P;
+  const int crow = (int)((P + kRowTile - 1) / kRowTile * kRowTile);
+  hipStream_t s = (hipStream_t)stream;
+  auto mark = [&](int stage) {
+    if (ga->stage_events && ga->stage_events[stage])
+      (void)hipEventRecord((hipEvent_t)ga->stage_events[stage], s);
+  };
+  hipError_t e = hipSuccess;
+#define LIST_TRY(call, what) do { e = (call); if (e != hipSuccess) return hip_fail(e, what); } while (0)
+
+  const int* order = a->no_sort ? nullptr : (const int*)(fw + ws.order);
+  float* scale = (float*)(bwp + bw.scale);
+  float* colsum = (float*)(bwp + bw.colsum);
+  float* slab = (float*)(bwp + bw.slab);
+  auto plane = [&](size_t off) { return (unsigned short*)(bwp + off); };
+
+  mark(LIST_BWD_BEGIN);
+  // --- head: scale, fc_2 re-evaluation (H3), dZ3, d fc_out ----------------------------------------------
+  LIST_TRY(launch_grad_scale(ga->grad_sdf, P, fp16 ? 1 : 0, scale, ga->mlp.b3, colsum, s), "grad_scale launch");
+  GemmParams gp;
+  memset(&gp, 0, sizeof(gp));
+  gp.fmt = fmt;
+  gp.a_hi = fw + ws.h2_hi; gp.a_lo = fw + ws.h2_lo;
+  gp.w_hi = wp + pk.w2_hi; gp.w_lo = wp + pk.w2_lo;
+  gp.bias = (const float*)(wp + pk.b2);
+  gp.M = crow; gp.N = a->H3; gp.K = a->H2;
+  gp.out_hi = plane(bw.h3_hi); gp.out_lo = lo ? plane(bw.h3_lo) : nullptr; gp.ldo = a->H3;
+  LIST_TRY(launch_gemm(gp, terms, EPI_RELU_SPLIT, s), "fc_2 re-evaluation launch");
+  LIST_TRY(launch_head(ga->grad_sdf, order, n_valid, crow, a->H3, plane(bw.h3_hi), (const float*)(wp + pk.w3),
+                       scale, plane(bw.dz3_hi), lo ? plane(bw.dz3_lo) : nullptr, fmt, s), "head launch");
+  if (ga->mlp.w3)
+    LIST_TRY(launch_colsum(plane(bw.h3_hi), lo ? plane(bw.h3_lo) : nullptr, crow, n_valid, a->H3, fmt,
+                           ga->grad_sdf, order, scale, 0, colsum, ga->mlp.w3, s), "d fc_out.weight launch");
+  if (ga->mlp.b2)
+    LIST_TRY(launch_colsum(plane(bw.dz3_hi), lo ? plane(bw.dz3_lo) : nullptr, crow, n_valid, a->H3, fmt, nullptr,
+                           nullptr, scale, 1, colsum, ga->mlp.b2, s), "d fc_2.bias launch");
+  mark(LIST_BWD_HEAD);
+
+  // one layer of the chain: weight gradient (TN), bias gradient, then the masked data gradient (NT)
+  auto wgrad = [&](size_t dz_hi, size_t dz_lo, int M, const char* act_hi, const char* act_lo, int N, int ldb,
+                   const FeatLayout* layout, float* out, int ldo) -> hipError_t {
+    if (!out) return hipSuccess;
+    GemmTnParams tp;
+    memset(&tp, 0, sizeof(tp));
+    tp.a_hi = bwp + dz_hi; tp.a_lo = lo ? bwp + dz_lo : nullptr; tp.lda = M;
+    tp.b_hi = act_hi; tp.b_lo = lo ? act_lo : nullptr; tp.ldb = ldb;
+    tp.M = M; tp.N = N; tp.P = crow;
+    tp.splits = wgrad_splits(M, N, crow, terms);
+    const int nk = crow / (terms == 3 ? 32 : 64);
+    tp.steps_per_split = (nk + tp.splits - 1) / tp.splits;
+    tp.slab = slab; tp.ldn = N; tp.fmt = fmt;
+    hipError_t err = launch_gemm_tn(tp, terms, s);
+    if (err != hipSuccess) return err;
+    return launch_wgrad_reduce(slab, tp.splits, M, N, N, layout, scale, out, ldo, s);
+  };
+  auto dgrad = [&](size_t dz_hi, size_t dz_lo, int K, const char* wt_hi, const char* wt_lo, int N,
+                   const char* mask_hi, size_t out_hi, size_t out_lo) -> hipError_t {
+    GemmParams d;
+    memset(&d, 0, sizeof(d));
+    d.fmt = fmt;
+    d.a_hi = bwp + dz_hi; d.a_lo = bwp + dz_lo;
+    d.w_hi = wt_hi; d.w_lo = wt_lo;
+    d.M = crow; d.N = N; d.K = K;
+    d.out_hi = plane(out_hi); d.out_lo = lo ? plane(out_lo) : nullptr; d.ldo = N;
+    d.mask = (const unsigned short*)mask_hi; d.ldmask = N;
+    return launch_gemm(d, terms, EPI_MASK_SPLIT, s);
+  };
+
+  // fc_2
+  LIST_TRY(wgrad(bw.dz3_hi, bw.dz3_lo, a->H3, fw + ws.h2_hi, fw + ws.h2_lo, a->H2, a->H2, nullptr, ga->mlp.w2,
+                 a->H2), "dW2 launch");
+  mark(LIST_BWD_WGRAD2);
+  LIST_TRY(dgrad(bw.dz3_hi, bw.dz3_lo, a->H3, wt + pb.w2t_hi, wt + pb.w2t_lo, a->H2, fw + ws.h2_hi, bw.dz2_hi,
+                 bw.dz2_lo), "dH2 launch");
+  mark(LIST_BWD_DGRAD2);
+  // fc_1
+  if (ga->mlp.b1)
+    LIST_TRY(launch_colsum(plane(bw.dz2_hi), lo ? plane(bw.dz2_lo) : nullptr, crow, n_valid, a->H2, fmt, nullptr,
+                           nullptr, scale, 1, colsum, ga->mlp.b1, s), "d fc_1.bias launch");
+  LIST_TRY(wgrad(bw.dz2_hi, bw.dz2_lo, a->H2, fw + ws.h1_hi, fw + ws.h1_lo, a->H1, a->H1, nullptr, ga->mlp.w1,
+                 a->H1), "dW1 launch");
+  mark(LIST_BWD_WGRAD1);
+  LIST_TRY(dgrad(bw.dz2_hi, bw.dz2_lo, a->H2, wt + pb.w1t_hi, wt + pb.w1t_lo, a->H1, fw + ws.h1_hi, bw.dz1_hi,
+                 bw.dz1_lo), "dH1 launch");
+  mark(LIST_BWD_DGRAD1);
+  // fc_0
+  if (ga->mlp.b0)
+    LIST_TRY(launch_colsum(plane(bw.dz1_hi), lo ? plane(bw.dz1_lo) : nullptr, crow, n_valid, a->H1, fmt, nullptr,
+                           nullptr, scale, 1, colsum, ga->mlp.b0, s), "d fc_0.bias launch");
+  LIST_TRY(wgrad(bw.dz1_hi, bw.dz1_lo, a->H1, fw + ws.x_hi, fw + ws.x_lo, L.Kp, L.Kp, &L, ga->mlp.w0, L.F),
+           "dW0 launch");
+  mark(LIST_BWD_WGRAD0);
+
+  bool want_maps = ga->grad_img_map || ga->grad_trans_mat;
+  for (int l = 0; l < LIST_N_VOX_LEVELS; ++l) want_maps = want_maps || ga->grad_vox[l].data;
+  if (!want_maps) {
+    for (int st = LIST_BWD_DGRAD0; st < LIST_N_BWD_STAGES; ++st) mark(st);
+    return LIST_OK;
+  }
+  {
+    GemmParams d;
+    memset(&d, 0, sizeof(d));
+    d.fmt = fmt;
+    d.a_hi = bwp + bw.dz1_hi; d.a_lo = bwp + bw.dz1_lo;
+    d.w_hi = wt + pb.w0t_hi; d.w_lo = wt + pb.w0t_lo;
+    d.M = crow; d.N = pb.KpT; d.K = a->H1;
+    d.dx = bwp + bw.dx; d.dx_f16 = fp16 ? 1 : 0; d.n_store = L.Kp; d.ldo = L.Kp;
+    LIST_TRY(launch_gemm(d, terms, EPI_DX, s), "dX launch");
+  }
+  mark(LIST_BWD_DGRAD0);
+
+  ScatterParams sp;
+  sp.g = make_gather(a, L, ws, 0, n_valid, crow);
+  sp.g.order = order;
+  const bool pix = !a->no_sort && a->map_size * ((a->map_size + 3) / 4) <= kSortPixCells;
+  if (pix) { sp.g.order_img = (const int*)(fw + ws.order_img); sp.g.row_of = (const int*)(fw + ws.row_of); }
+  sp.dx = bwp + bw.dx; sp.dx_f16 = fp16 ? 1 : 0; sp.scale = scale;
+  LIST_TRY(launch_scatter_vox(sp, L, *a, ga->grad_vox, s), "voxel scatter launch");
+  mark(LIST_BWD_VOX);
+  const int nslots = a->B < kSortImages ? a->B : kSortImages;
+  const int* bins_pix = pix ? (const int*)(fw + ws.bins) + (size_t)nslots * kSortCells : nullptr;
+  if (pix && a->B > kSortImages) { sp.g.order_img = nullptr; sp.g.row_of = nullptr; bins_pix = nullptr; }
+  LIST_TRY(launch_img_grad(sp, L, *a, bins_pix, nslots, bwp + bw.recs, ga->grad_img_map, ga->grad_trans_mat,
+                           ga->stage_events, s), "image gradient launch");
+#undef LIST_TRY
+  return LIST_OK;
+}
+
+int list_img_map_grad_to_levels(const float* grad_img_map, int32_t B, int32_t map_size,
+                                const ListMap2D grads[LIST_N_IMG_LEVELS], void* stream) {
+  if (!grad_img_map || !grads) return fail(LIST_ERR_ARG, "NULL pointer");
+  if (B <= 0 || map_size < 2 || map_size > 320)
+    return fail(LIST_ERR_SHAPE, "B=%d map_size=%d (need 2..320)", B, map_size);
+  int Ct = 0;
+  for (int i = 0; i < LIST_N_IMG_LEVELS; ++i) {
+    if (grads[i].C < 1 || grads[i].H < 1 || grads[i].W < 1)
+      return fail(LIST_ERR_SHAPE, "image level %d: bad descriptor", i);
+    Ct += grads[i].C;
+  }
+  hipError_t e = launch_img_grad_to_levels(grad_img_map, B, map_size, Ct, grads, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "img_grad_to_levels launch");
+  return LIST_OK;
+}
+
+int list_gemm_tn(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* out,
+                 void* slab, size_t slab_bytes, int32_t M, int32_t N, int32_t P, int32_t precision,
+                 void* stream) {
+  if (!a_hi || !b_hi || !out || !slab) return fail(LIST_ERR_ARG, "NULL pointer");
+  if (precision < LIST_PREC_BF16X3 || precision > LIST_PREC_FP16) return fail(LIST_ERR_ARG, "precision=%d", precision);
+  if (precision == LIST_PREC_BF16X3 && (!a_lo || !b_lo)) return fail(LIST_ERR_ARG, "lo planes missing");
+  if (M <= 0 || M % 256 || N < 8 || N % 8 || P <= 0 || P % 256)
+    return fail(LIST_ERR_SHAPE, "M=%d N=%d P=%d (need M,P %% 256 == 0, N %% 8 == 0)", M, N, P);
+  if (!aligned16(a_hi) || !aligned16(b_hi) || (a_lo && !aligned16(a_lo)) || (b_lo && !aligned16(b_lo)))
+    return fail(LIST_ERR_SHAPE, "operands must be 16-byte aligned");
+  const int terms = precision == LIST_PREC_BF16X3 ? 3 : 1;
+  GemmTnParams tp;
+  memset(&tp, 0, sizeof(tp));
+  tp.a_hi = (const char*)a_hi; tp.a_lo = (const char*)a_lo; tp.lda = M;
+  tp.b_hi = (const char*)b_hi; tp.b_lo = (const char*)b_lo; tp.ldb = N;
+  tp.M = M; tp.N = N; tp.P = P;
+  tp.splits = wgrad_splits(M, N, P, terms);
+  const int nk = P / (terms == 3 ? 32 : 64);
+  tp.steps_per_split = (nk + tp.splits - 1) / tp.splits;
+  tp.slab = (float*)slab; tp.ldn = N; tp.fmt = precision == LIST_PREC_FP16 ? FMT_FP16 : FMT_BF16_SPLIT;
+  if (slab_bytes < (size_t)tp.splits * M * N * 4)
+    return fail(LIST_ERR_WORKSPACE, "slab too small: %zu < %zu", slab_bytes, (size_t)tp.splits * M * N * 4);
+  hipError_t e = launch_gemm_tn(tp, terms, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "gemm_tn launch");
+  e = launch_wgrad_reduce(tp.slab, tp.splits, M, N, N, nullptr, nullptr, out, N, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "wgrad_reduce launch");
+  return LIST_OK;
+}
+
 // ------------------------------------------------------------------------------------------ diagnostics
 int list_gemm_nt(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo,
                  const float* bias, float* out, int32_t M, int32_t N, int32_t K, int32_t relu,

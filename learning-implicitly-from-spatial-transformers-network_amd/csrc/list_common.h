@@ -169,6 +169,73 @@ inline PackedMlp packed_mlp_layout(int Kp, int H1, int H2, int H3) {
   return p;
 }
 
+// ---- transposed weight copies for the backward (output of list_prep_mlp_weights_bwd) ---------------
+// dgrad runs on the same NT kernel: dH[P][K_in] = dZ[P][N_out] . (W^T)[K_in][N_out]^T, so each layer
+// needs W^T [K_in][N_out] (row-major, 16-bit planes).  fc_0's K_in = Kp is padded to 256 rows (zeros).
+struct PackedMlpBwd {
+  size_t w0t_hi, w0t_lo;      // [KpT][H1],  KpT = Kp rounded up to 256
+  size_t w1t_hi, w1t_lo;      // [H1][H2]
+  size_t w2t_hi, w2t_lo;      // [H2][H3]
+  size_t total;
+  int KpT;
+};
+inline PackedMlpBwd packed_mlp_bwd_layout(int Kp, int H1, int H2, int H3) {
+  PackedMlpBwd p;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+  p.KpT = (Kp + 255) / 256 * 256;
+  p.w0t_hi = take((size_t)p.KpT * H1 * 2); p.w0t_lo = take((size_t)p.KpT * H1 * 2);
+  p.w1t_hi = take((size_t)H1 * H2 * 2); p.w1t_lo = take((size_t)H1 * H2 * 2);
+  p.w2t_hi = take((size_t)H2 * H3 * 2); p.w2t_lo = take((size_t)H2 * H3 * 2);
+  p.total = o;
+  return p;
+}
+
+// ---- backward workspace -----------------------------------------------------------------------------------
+constexpr int kColsumRows = 256;         // rows per partial of the bias-gradient column sums
+constexpr int kWgradMaxSplits = 128;
+
+struct BwdWorkspace {
+  size_t scale;                              // float[4]: s, 1/s, sum(dsdf), -
+  size_t h3_hi, h3_lo;                       // fc_2 activations, re-evaluated
+  size_t dz3_hi, dz3_lo, dz2_hi, dz2_lo, dz1_hi, dz1_lo;
+  size_t dx;                                 // [rows][Kp] fp16 (FP16) or fp32
+  size_t slab;                               // wgrad partials, fp32
+  size_t colsum;                             // bias-gradient partials
+  size_t recs;                               // per-point projection records (2-D gradient)
+  size_t total;
+};
+inline int wgrad_nominal_splits(int M, int N) {     // enough workgroups to fill 256 CUs twice
+  const int tiles = (M / 256) * ((N + 255) / 256);
+  int s = 512 / (tiles > 0 ? tiles : 1);
+  return s > kWgradMaxSplits ? kWgradMaxSplits : (s < 1 ? 1 : s);
+}
+inline size_t wgrad_slab_bytes(int Kp, int H1, int H2, int H3) {
+  size_t big = (size_t)H1 * Kp * wgrad_nominal_splits(H1, Kp);
+  const size_t b1 = (size_t)H2 * H1 * wgrad_nominal_splits(H2, H1);
+  const size_t b2 = (size_t)H3 * H2 * wgrad_nominal_splits(H3, H2);
+  if (b1 > big) big = b1;
+  if (b2 > big) big = b2;
+  return big * 4;
+}
+inline BwdWorkspace bwd_workspace_layout(int64_t rows, int Kp, int H1, int H2, int H3, bool fp16) {
+  BwdWorkspace w;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+  w.scale = take(16);
+  w.h3_hi = take((size_t)rows * H3 * 2); w.h3_lo = take((size_t)rows * H3 * 2);
+  w.dz3_hi = take((size_t)rows * H3 * 2); w.dz3_lo = take((size_t)rows * H3 * 2);
+  w.dz2_hi = take((size_t)rows * H2 * 2); w.dz2_lo = take((size_t)rows * H2 * 2);
+  w.dz1_hi = take((size_t)rows * H1 * 2); w.dz1_lo = take((size_t)rows * H1 * 2);
+  w.dx = take((size_t)rows * Kp * (fp16 ? 2 : 4));
+  w.slab = take(wgrad_slab_bytes(Kp, H1, H2, H3));
+  const int hmax = H1 > H2 ? (H1 > H3 ? H1 : H3) : (H2 > H3 ? H2 : H3);
+  w.colsum = take((size_t)((rows + kColsumRows - 1) / kColsumRows) * hmax * 4);
+  w.recs = take((size_t)rows * 32);
+  w.total = o;
+  return w;
+}
+
 // ---- per-chunk workspace --------------------------------------------------------------------
 constexpr int kSortCellsPerAxis = 16;                        // Morton cells per axis per image
 constexpr int kSortCells = kSortCellsPerAxis * kSortCellsPerAxis * kSortCellsPerAxis;   // 4096
@@ -227,9 +294,23 @@ struct GemmParams {
   const float* w3; const float* b3; float* sdf; int n_valid; // EPI_RELU_DOT
   const int* order;                                          // sdf[order[row]] if not null
   int fmt;                                                   // FMT_BF16_SPLIT or FMT_FP16
+  const unsigned short* mask; int ldmask;                    // EPI_MASK_SPLIT: keep acc where mask plane != 0
+  void* dx; int dx_f16; int n_store;                         // EPI_DX: [M][ldo] fp16/fp32, columns < n_store
 };
 
-enum { EPI_RELU_SPLIT = 0, EPI_F32 = 1, EPI_RELU_DOT = 2 };
+// EPI_MASK_SPLIT: out = acc where the saved activation is positive (ReLU backward), no bias;
+// EPI_DX: plain store of acc (fp16 or fp32) with a column guard (N is padded to the tile).
+enum { EPI_RELU_SPLIT = 0, EPI_F32 = 1, EPI_RELU_DOT = 2, EPI_MASK_SPLIT = 3, EPI_DX = 4 };
+
+// out[m][n] = sum_p A[p][m] * B[p][n]  (weight gradients: A = dZ, B = X / H); split over p into slabs
+struct GemmTnParams {
+  const char* a_hi; const char* a_lo; int lda;     // [P][lda] 16-bit planes
+  const char* b_hi; const char* b_lo; int ldb;     // [P][ldb]
+  int M, N, P;                                     // M % 256 == 0, N % 8 == 0, P % 256 == 0
+  int splits, steps_per_split;                     // K-steps (of BK rows) per split
+  float* slab; int ldn;                            // [splits][M][ldn] fp32
+  int fmt;
+};
 
 // ---- launchers (defined in the .hip files) ----------------------------------------------------
 hipError_t launch_prep_img(const ListMap2D maps[LIST_N_IMG_LEVELS], int B, int map_size, int Ct,
@@ -248,5 +329,39 @@ hipError_t launch_features_out(const GatherParams& g, const FeatLayout& L, float
                                hipStream_t s);
 hipError_t launch_percep_pool(const ListPoolArgs& a, hipStream_t s);
 hipError_t launch_gemm(const GemmParams& p, int terms, int epi, hipStream_t s);
+
+// backward: MLP (bwd_mlp_kernels.hip)
+hipError_t launch_prep_weights_bwd(const ListMlpWeights& w, const FeatLayout& L, const PackedMlpBwd& P,
+                                   char* packed, hipStream_t s);
+hipError_t launch_gemm_tn(const GemmTnParams& p, int terms, hipStream_t s);
+int wgrad_splits(int M, int N, int P, int terms);
+// out[m][col(n)] = inv_scale * sum_s slab[s][m][n]; L != nullptr: n is a gather-order column of fc_0,
+// written to its reference column (padding dropped); ldo = row stride of out
+hipError_t launch_wgrad_reduce(const float* slab, int splits, int M, int N, int ldn, const FeatLayout* L,
+                               const float* scale, float* out, int ldo, hipStream_t s);
+hipError_t launch_grad_scale(const float* grad_sdf, int64_t n, int fp16, float* scale, float* db3,
+                             float* partial, hipStream_t s);
+hipError_t launch_head(const float* grad_sdf, const int* order, int n_valid, int rows, int H3,
+                       const unsigned short* h3_hi, const float* w3, const float* scale,
+                       unsigned short* dz_hi, unsigned short* dz_lo, int fmt, hipStream_t s);
+// out[n] = f * sum_r w_r * Z[r][n]; w_r = grad_sdf[order[r]] (rows < n_valid) if weights else 1;
+// f = scale[1] if use_inv_scale else 1
+hipError_t launch_colsum(const unsigned short* z_hi, const unsigned short* z_lo, int rows, int n_valid,
+                         int N, int fmt, const float* grad_sdf, const int* order, const float* scale,
+                         int use_inv_scale, float* partial, float* out, hipStream_t s);
+
+// backward: maps (bwd_scatter_kernels.hip)
+struct ScatterParams {
+  GatherParams g;             // points (x_hi/x_lo unused)
+  const void* dx; int dx_f16; // [rows][Kp]
+  const float* scale;         // [0] = s, [1] = 1/s
+};
+hipError_t launch_scatter_vox(const ScatterParams& sp, const FeatLayout& L, const ListQueryArgs& a,
+                              const ListVoxLevel grad_vox[LIST_N_VOX_LEVELS], hipStream_t s);
+hipError_t launch_img_grad(const ScatterParams& sp, const FeatLayout& L, const ListQueryArgs& a,
+                           const int* bins_pix, int nslots, void* recs, float* grad_img_map,
+                           float* grad_trans_mat, void* const* stage_events, hipStream_t s);
+hipError_t launch_img_grad_to_levels(const float* grad_img_map, int B, int map_size, int Ct,
+                                     const ListMap2D grads[LIST_N_IMG_LEVELS], hipStream_t s);
 
 }  // namespace list

@@ -71,6 +71,24 @@ class ListQueryArgs(C.Structure):
                 ("stage_events", C.POINTER(C.c_void_p)), ("no_sort", C.c_int32)]
 
 
+class ListMlpGrads(C.Structure):
+    _fields_ = [("w0", C.c_void_p), ("b0", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p),
+                ("w2", C.c_void_p), ("b2", C.c_void_p), ("w3", C.c_void_p), ("b3", C.c_void_p)]
+
+
+class ListQueryGradArgs(C.Structure):
+    _fields_ = [("fwd", C.POINTER(ListQueryArgs)), ("grad_sdf", C.c_void_p),
+                ("packed_mlp_bwd", C.c_void_p), ("mlp", ListMlpGrads),
+                ("grad_img_map", C.c_void_p), ("grad_trans_mat", C.c_void_p),
+                ("grad_vox", ListVoxLevel * N_VOX_LEVELS),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("stage_events", C.POINTER(C.c_void_p))]
+
+
+N_BWD_STAGES = 11
+BWD_STAGE_NAMES = ("head", "wgrad_fc2", "dgrad_fc2", "wgrad_fc1", "dgrad_fc1", "wgrad_fc0", "dgrad_fc0",
+                   "scatter_vox", "img_map_grad", "trans_mat_grad")
+
 N_STAGES = 12
 # interval i = [event i, event i+1]: the kernel (group) that ends at stage i+1 of include/list_hip.h
 STAGE_NAMES = ("sort_points", "gather_vox_l1", "gather_vox_l2", "gather_vox_l3", "gather_vox_l4",
@@ -106,6 +124,15 @@ EXPORTS = {
                                C.c_void_p]),
     "list_split_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "list_to_fp16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "list_packed_mlp_bwd_bytes": (C.c_size_t, [C.POINTER(ListMlpWeights)]),
+    "list_prep_mlp_weights_bwd": (C.c_int, [C.POINTER(ListMlpWeights), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "list_query_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                                    C.c_int32]),
+    "list_sdf_query_bwd": (C.c_int, [C.POINTER(ListQueryGradArgs), C.c_void_p]),
+    "list_img_map_grad_to_levels": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(ListMap2D),
+                                              C.c_void_p]),
+    "list_gemm_tn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "list_last_error": (C.c_char_p, []),
     "list_abi_version": (C.c_int, []),
 }
@@ -222,10 +249,7 @@ def prep_vox_maps(vox_feat, dtype="f32"):
     return PreparedVoxels(levels, (pack, list(vox_feat)))
 
 
-def prep_mlp_weights(params, vox_C, img_C=1024, precision="bf16x3"):
-    """params: dict with fc_0/fc_1/fc_2/fc_out .weight/.bias (reference state_dict names,
-    network/modules.py:196-200).  Conv1d weights may be [out,in,1] or [out,in]."""
-    lib = load()
+def _mlp_weights_struct(params, vox_C, img_C, precision):
     ts = {}
     for name in ("fc_0", "fc_1", "fc_2", "fc_out"):
         w = _f32_cuda(params[name + ".weight"], name + ".weight").detach()
@@ -245,6 +269,14 @@ def prep_mlp_weights(params, vox_C, img_C=1024, precision="bf16x3"):
         w.vox_C[i] = int(c)
     w.img_C = int(img_C)
     w.precision = PRECISIONS[precision] if isinstance(precision, str) else int(precision)
+    return w, ts
+
+
+def prep_mlp_weights(params, vox_C, img_C=1024, precision="bf16x3"):
+    """params: dict with fc_0/fc_1/fc_2/fc_out .weight/.bias (reference state_dict names,
+    network/modules.py:196-200).  Conv1d weights may be [out,in,1] or [out,in]."""
+    lib = load()
+    w, ts = _mlp_weights_struct(params, vox_C, img_C, precision)
     need = lib.list_packed_mlp_bytes(C.byref(w))
     if need == 0:
         raise RuntimeError("list_packed_mlp_bytes failed: "
@@ -257,6 +289,22 @@ def prep_mlp_weights(params, vox_C, img_C=1024, precision="bf16x3"):
     # temporaries made by .contiguous() are released stream-ordered by the caching allocator, and
     # every kernel above was enqueued on the same (current) stream: no synchronisation needed
     return PackedMlp(packed, w.F, w.H1, w.H2, w.H3, vox_C, img_C, w.precision == PREC_FP16)
+
+
+def prep_mlp_weights_bwd(params, vox_C, img_C=1024, precision="bf16x3"):
+    """Transposed 16-bit copies of fc_0..fc_2 for the data-gradient GEMMs of list_sdf_query_bwd."""
+    lib = load()
+    w, ts = _mlp_weights_struct(params, vox_C, img_C, precision)
+    need = lib.list_packed_mlp_bwd_bytes(C.byref(w))
+    if need == 0:
+        raise RuntimeError("list_packed_mlp_bwd_bytes failed: "
+                           + lib.list_last_error().decode("utf-8", "replace"))
+    dev = ts["fc_0"][0].device
+    packed = torch.empty((need,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib.list_prep_mlp_weights_bwd(C.byref(w), packed.data_ptr(), need, _stream()),
+               "list_prep_mlp_weights_bwd")
+    return packed
 
 
 _workspaces = {}
@@ -279,7 +327,7 @@ def release_workspaces():
 
 
 def _fill_query_args(query, perm, scale, vox, packed, precision, trans_mat=None, img=None,
-                     percep_feat=None, clamp_hi=136.0):
+                     percep_feat=None, clamp_hi=136.0, private_workspace=False):
     lib = load()
     _f32_cuda(query, "query")
     if query.dim() != 3 or query.shape[2] != 3:
@@ -318,23 +366,36 @@ def _fill_query_args(query, perm, scale, vox, packed, precision, trans_mat=None,
         raise RuntimeError("packed MLP weights were prepared for a different precision "
                            "(fp16 vs bf16 planes); call prep_mlp_weights(..., precision=...) again")
     nbytes = lib.list_query_workspace_bytes(B * N, a.F, a.H1, a.H2, a.H3)
-    ws = _workspace(query.device, nbytes)
+    # a call whose backward will run later keeps its own workspace (X, H1, H2, point order live there)
+    ws = (torch.empty((nbytes,), dtype=torch.uint8, device=query.device) if private_workspace
+          else _workspace(query.device, nbytes))
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     keep.append(ws)
     return a, keep
 
 
+class QueryContext:
+    """What list_sdf_query_bwd needs from a forward call: its argument block (pointers into tensors
+    kept alive here) including the private workspace."""
+
+    def __init__(self, args, keep, vox, img):
+        self.args, self.keep, self.vox, self.img = args, keep, vox, img
+
+
 def sdf_query(query, trans_mat, img, vox, packed, perm=(2, 1, 0), scale=2.0, precision="bf16x3",
-              percep_feat=None, out=None, stage_events=None, sort_points=True, clamp_hi=136.0):
+              percep_feat=None, out=None, stage_events=None, sort_points=True, clamp_hi=136.0,
+              save_for_backward=False):
     """The fused hot path, network/models.py:91-97 -> sdf [B,N] (float32).
 
-    stage_events: optional ctypes array (c_void_p * N_STAGES) of hipEvent_t handles."""
+    stage_events: optional ctypes array (c_void_p * N_STAGES) of hipEvent_t handles.
+    save_for_backward: return (sdf, QueryContext) for sdf_query_backward."""
     lib = load()
     if query.dim() == 3 and query.shape[0] * query.shape[1] == 0:      # empty query -> empty field
         _f32_cuda(query, "query")
-        return torch.empty(query.shape[:2], dtype=torch.float32, device=query.device)
+        empty = torch.empty(query.shape[:2], dtype=torch.float32, device=query.device)
+        return (empty, None) if save_for_backward else empty
     a, keep = _fill_query_args(query, perm, scale, vox, packed, precision, trans_mat, img, percep_feat,
-                               clamp_hi)
+                               clamp_hi, private_workspace=save_for_backward)
     a.no_sort = 0 if sort_points else 1
     if stage_events is not None:
         a.stage_events = C.cast(stage_events, C.POINTER(C.c_void_p))
@@ -345,7 +406,104 @@ def sdf_query(query, trans_mat, img, vox, packed, perm=(2, 1, 0), scale=2.0, pre
     a.sdf = sdf.data_ptr()
     with torch.cuda.device(query.device):
         _check(lib.list_sdf_query_fwd(C.byref(a), _stream()), "list_sdf_query_fwd")
+    if save_for_backward:
+        a.stage_events = None
+        return sdf, QueryContext(a, keep + [packed, sdf], vox, img)
     return sdf
+
+
+def sdf_query_backward(ctx, grad_sdf, packed_bwd, want_mlp=True, want_img=True, want_vox=True,
+                       want_trans=True, stage_events=None):
+    """Backward of sdf_query (list_sdf_query_bwd).  Returns a dict:
+      'mlp'       : {fc_0.weight [H1,F,1], fc_0.bias, ..., fc_out.bias} (reference layouts)
+      'img_map'   : gradient of the prepared perceptual map, float32 [B,ms,ms,Ct]
+      'vox'       : per level float32 [B,D,H,W,C] (channels-last; .permute(0,4,1,2,3) is the NCDHW view)
+      'trans_mat' : [B,4,3]"""
+    lib = load()
+    a = ctx.args
+    B, N = a.B, a.N
+    dev = grad_sdf.device
+    g = _f32_cuda(grad_sdf, "grad_sdf").reshape(B, N).contiguous()
+    ga = ListQueryGradArgs()
+    ga.fwd = C.pointer(a)
+    ga.grad_sdf = g.data_ptr()
+    ga.packed_mlp_bwd = packed_bwd.data_ptr()
+    out = {}
+    f32 = dict(dtype=torch.float32, device=dev)
+    if want_mlp:
+        m = {"fc_0.weight": torch.empty((a.H1, a.F, 1), **f32), "fc_0.bias": torch.empty((a.H1,), **f32),
+             "fc_1.weight": torch.empty((a.H2, a.H1, 1), **f32), "fc_1.bias": torch.empty((a.H2,), **f32),
+             "fc_2.weight": torch.empty((a.H3, a.H2, 1), **f32), "fc_2.bias": torch.empty((a.H3,), **f32),
+             "fc_out.weight": torch.empty((1, a.H3, 1), **f32), "fc_out.bias": torch.empty((1,), **f32)}
+        ga.mlp.w0, ga.mlp.b0 = m["fc_0.weight"].data_ptr(), m["fc_0.bias"].data_ptr()
+        ga.mlp.w1, ga.mlp.b1 = m["fc_1.weight"].data_ptr(), m["fc_1.bias"].data_ptr()
+        ga.mlp.w2, ga.mlp.b2 = m["fc_2.weight"].data_ptr(), m["fc_2.bias"].data_ptr()
+        ga.mlp.w3, ga.mlp.b3 = m["fc_out.weight"].data_ptr(), m["fc_out.bias"].data_ptr()
+        out["mlp"] = m
+    if want_img:
+        out["img_map"] = torch.empty((B, a.map_size, a.map_size, a.img_C), **f32)
+        ga.grad_img_map = out["img_map"].data_ptr()
+    if want_trans:
+        out["trans_mat"] = torch.empty((B, 4, 3), **f32)
+        ga.grad_trans_mat = out["trans_mat"].data_ptr()
+    if want_vox:
+        out["vox"] = []
+        for i in range(N_VOX_LEVELS):
+            lv = a.vox[i]
+            t = torch.empty((B, lv.D, lv.H, lv.W, lv.C), **f32)
+            out["vox"].append(t)
+            ga.grad_vox[i] = ListVoxLevel(t.data_ptr(), lv.C, lv.D, lv.H, lv.W, MAP_F32, 0,
+                                          lv.C * lv.D * lv.H * lv.W)
+    nbytes = lib.list_query_bwd_workspace_bytes(B * N, a.F, a.H1, a.H2, a.H3, a.precision)
+    if nbytes == 0:
+        raise RuntimeError(f"list_sdf_query_bwd handles at most 262144 points per call (got {B * N})")
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    ga.workspace, ga.workspace_bytes = ws.data_ptr(), nbytes
+    if stage_events is not None:
+        ga.stage_events = C.cast(stage_events, C.POINTER(C.c_void_p))
+    with torch.cuda.device(dev):
+        _check(lib.list_sdf_query_bwd(C.byref(ga), _stream()), "list_sdf_query_bwd")
+    return out
+
+
+def img_map_grad_to_levels(grad_img_map, like):
+    """Adjoint of prep_img_maps: gradient of the prepared map [B,ms,ms,Ct] -> one gradient per encoder
+    level, shaped (and strided) like the tensors in `like`."""
+    lib = load()
+    g = _f32_cuda(grad_img_map, "grad_img_map").contiguous()
+    B, ms = g.shape[0], g.shape[1]
+    maps = (ListMap2D * N_IMG_LEVELS)()
+    outs = []
+    for i, t in enumerate(like):
+        o = torch.empty_like(t)
+        outs.append(o)
+        maps[i] = ListMap2D(o.data_ptr(), o.shape[1], o.shape[2], o.shape[3], *o.stride())
+    if sum(o.shape[1] for o in outs) != g.shape[3]:
+        raise RuntimeError("channel counts of `like` do not add up to the prepared map's")
+    with torch.cuda.device(g.device):
+        _check(lib.list_img_map_grad_to_levels(g.data_ptr(), B, ms, maps, _stream()),
+               "list_img_map_grad_to_levels")
+    return outs
+
+
+def gemm_tn(a, b, precision="bf16x3"):
+    """Diagnostic: out[M,N] = a[P,M]^T @ b[P,N] through the weight-gradient MFMA kernel."""
+    lib = load()
+    P, M = a.shape
+    N = b.shape[1]
+    if precision == "fp16":
+        a_hi, b_hi = to_fp16(a), to_fp16(b)
+        a_lo, b_lo = a_hi, b_hi
+    else:
+        a_hi, a_lo = split_bf16(a)
+        b_hi, b_lo = split_bf16(b)
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    slab = torch.empty((128 * M * N,), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        _check(lib.list_gemm_tn(a_hi.data_ptr(), a_lo.data_ptr(), b_hi.data_ptr(), b_lo.data_ptr(),
+                                out.data_ptr(), slab.data_ptr(), slab.numel() * 4, M, N, P,
+                                PRECISIONS[precision], _stream()), "list_gemm_tn")
+    return out
 
 
 def gather_features(query, trans_mat, img, vox, packed, perm=(2, 1, 0), scale=2.0,

@@ -24,6 +24,15 @@ def build_case(name):
         return _case(seed=333, batch=1, n=64, img_res=224, vox_res=128)
     if name == "edge":
         return _edge_case()
+    # gradient cases: same shapes, seeds chosen so that no ReLU pre-activation of the fp32 forward is
+    # closer to zero than 4e-6 (the mask is discontinuous: a sign flip from 1e-6-level arithmetic
+    # differences would change the gradients by percents; searched with tools/find_margin_seeds.py)
+    if name == "gtiny":
+        return _case(seed=1116, batch=2, n=129, img_res=32, vox_res=16)
+    if name == "gsmall":
+        return _case(seed=2394, batch=3, n=67, img_res=64, vox_res=32)
+    if name == "gedge":
+        return _edge_case(seed=GEDGE_SEED)
     raise KeyError(name)
 
 
@@ -37,10 +46,10 @@ def _case(seed, batch, n, img_res, vox_res):
     }
 
 
-def _edge_case():
+def _edge_case(seed=404):
     """Points on the +-1 faces, projections clamped at 0 and at 136 (dropped tap),
     Z+1e-8 <= 0 (sign flip / inf -> clamp), displaced coordinates outside [-1,1]."""
-    c = _case(seed=404, batch=1, n=64, img_res=32, vox_res=16)
+    c = _case(seed=seed, batch=1, n=64, img_res=32, vox_res=16)
     q = c["query"].copy()
     corners = np.array([[s0, s1, s2] for s0 in (-0.5, 0.5) for s1 in (-0.5, 0.5)
                         for s2 in (-0.5, 0.5)], dtype=F32)
@@ -59,4 +68,6 @@ def _edge_case():
     return c
 
 
+GEDGE_SEED = 405
 CASE_NAMES = ("tiny", "small", "real", "edge")
+GRAD_CASE_NAMES = ("gtiny", "gsmall", "gedge")

@@ -105,7 +105,6 @@ def main():
     model_goldens(torch)
 
 
-GRAD_CASES = ("tiny", "small", "edge")
 GRAD_W0_ROW_STEP = 8
 
 
@@ -114,7 +113,7 @@ def grad_goldens(torch, dec, pool):
     taken by autograd THROUGH THE REFERENCE's modules (PerceptualPooling.forward + VoxelDecoder2.forward +
     the glue of models.py:91-97).  g = synth.normalish(seed 9000 + case index)."""
     from . import cases, synth
-    for ci, name in enumerate(GRAD_CASES):
+    for ci, name in enumerate(cases.GRAD_CASE_NAMES):
         c = cases.build_case(name)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).clone().requires_grad_(True)
         dec.load_state_dict({"fc." + k: torch.from_numpy(v.copy()) for k, v in c["weights"].items()})
@@ -139,7 +138,7 @@ def grad_goldens(torch, dec, pool):
         # keep the fixtures small: every 8th output row of fc_0's weight gradient, and for the larger
         # case every 2nd voxel / pixel of the map gradients (the tests apply the same slicing)
         out["d_fc_0.weight"] = out["d_fc_0.weight"][::GRAD_W0_ROW_STEP]
-        if name == "small":
+        if name == "gsmall":
             for i in range(len(vox_maps)):
                 out[f"d_vox{i}"] = out[f"d_vox{i}"][:, :, ::2, ::2, ::2]
             for i in range(len(img_maps)):

@@ -40,16 +40,16 @@ def test_torch_restatement_matches_reference(golden_dir, name):
     np.testing.assert_allclose(sdf, g["sdf"], rtol=0, atol=TOL_SDF)
 
 
-GRAD_CASES = ("tiny", "small", "edge")
+GRAD_CASES = cases.GRAD_CASE_NAMES
 
 
 def slice_like_golden(name, key, arr):
     """The slicing oracle/gen_golden.py:grad_goldens applied to keep the fixtures small."""
     if key == "d_fc_0.weight":
         return arr[::8]
-    if name == "small" and key.startswith("d_vox"):
+    if name == "gsmall" and key.startswith("d_vox"):
         return arr[:, :, ::2, ::2, ::2]
-    if name == "small" and key.startswith("d_img"):
+    if name == "gsmall" and key.startswith("d_img"):
         return arr[:, :, ::2, ::2]
     return arr
 
