@@ -234,7 +234,9 @@ int list_to_fp16(const float* x, void* out, int64_t n, void* stream);
  * fp32 epilogues), BF16 rounds gradient operands to bf16.  All sums are fp32.
  * Outputs are OVERWRITTEN (not accumulated); a NULL output is skipped.  Map and trans_mat
  * gradients use fp32 atomics where contributions collide, so their last bits may differ run to run;
- * the MLP parameter gradients are bitwise reproducible.
+ * the MLP parameter gradients are summed in a fixed order over the rows of the feature matrix and are
+ * bitwise reproducible for a fixed row order (no_sort = 1; the Morton order inside a sort bin is not
+ * deterministic).
  */
 typedef struct ListMlpGrads {         /* reference layouts, like ListMlpWeights */
   float* w0; float* b0;               /* [H1,F], [H1] */

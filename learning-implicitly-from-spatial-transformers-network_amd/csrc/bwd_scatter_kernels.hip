@@ -679,45 +679,50 @@ __device__ __forceinline__ void adj_footprint(int o, int S, int ms, int& i0, int
   w0 = 1.f - w1;
 }
 
+constexpr int kAdjTileW = 128;             // source columns per pass of phases 2-3
+
 __global__ __launch_bounds__(256) void k_img_grad_level(const float* __restrict__ G, int ms, int Ct, int coff,
-                                                        ListMap2D m) {
+                                                        ListMap2D m, int maxper) {
   extern __shared__ __attribute__((aligned(16))) float dyn[];
-  // dynamic LDS: R[ms][64] | tile[64][W + 1] | csr_w[2 ms] | csr_ox[2 ms] | csr_beg[W + 1] | oy list
+  // dynamic LDS: R[ms][64] | tile[64][kAdjTileW + 1] | wy[ms] | wx[W][maxper] | ox_first[W] | ox_cnt[W]
   float* R = dyn;
   float* tile = R + ms * 64;
-  float* csr_w = tile + 64 * (m.W + 1);
-  int* csr_ox = (int*)(csr_w + 2 * ms);
-  int* csr_beg = csr_ox + 2 * ms;
-  int* s_oy = csr_beg + (m.W + 1);
-  float* s_wy = (float*)(s_oy + ms);
-  __shared__ int s_ny;
+  float* s_wy = tile + 64 * (kAdjTileW + 1);
+  float* s_wx = s_wy + ms;
+  int* ox_first = (int*)(s_wx + m.W * maxper);
+  int* ox_cnt = ox_first + m.W;
+  __shared__ int oy_range[2];
   const int ys = blockIdx.x % m.H;
   const int b = blockIdx.x / m.H;
   const int c0 = blockIdx.y * 64;
-  if (threadIdx.x == 0) {
-    // rows of the map that touch source row ys (ascending oy), and the CSR of the x axis
-    int n = 0;
-    for (int o = 0; o < ms; ++o) {
-      int i0, i1; float w0, w1;
-      adj_footprint(o, m.H, ms, i0, i1, w0, w1);
-      if (i0 == ys || i1 == ys) { s_oy[n] = o; s_wy[n] = (i0 == ys ? w0 : 0.f) + (i1 == ys ? w1 : 0.f); ++n; }
-    }
-    s_ny = n;
+  if (threadIdx.x == 0) { oy_range[0] = INT_MAX; oy_range[1] = INT_MIN; }
+  __syncthreads();
+  // map rows that touch source row ys: footprints are monotone, so they form one contiguous range
+  for (int o = threadIdx.x; o < ms; o += 256) {
+    int i0, i1; float w0, w1;
+    adj_footprint(o, m.H, ms, i0, i1, w0, w1);
+    const bool hit = i0 == ys || i1 == ys;
+    s_wy[o] = hit ? (i0 == ys ? w0 : 0.f) + (i1 == ys ? w1 : 0.f) : 0.f;
+    if (hit) { atomicMin(&oy_range[0], o); atomicMax(&oy_range[1], o); }
   }
-  if (threadIdx.x == 64) {
-    // footprints are monotone in ox: xs collects a contiguous range of ox
-    int e = 0, o_lo = 0;
-    for (int xs = 0; xs < m.W; ++xs) {
-      csr_beg[xs] = e;
-      for (int o = o_lo; o < ms; ++o) {
-        int i0, i1; float w0, w1;
-        adj_footprint(o, m.W, ms, i0, i1, w0, w1);
-        if (i0 > xs) break;
-        if (i1 < xs) { o_lo = o + 1; continue; }
-        csr_ox[e] = o; csr_w[e] = (i0 == xs ? w0 : 0.f) + (i1 == xs ? w1 : 0.f); ++e;
-      }
+  // map columns that touch source column xs: first column, count, weights
+  const float scx = ms > 1 ? (float)(m.W - 1) / (float)(ms - 1) : 0.f;
+  for (int xs = threadIdx.x; xs < m.W; xs += 256) {
+    int o = 0;
+    if (scx > 0.f) o = max(0, (int)floorf((float)(xs - 1) / scx) - 2);
+    int i0, i1; float w0, w1;
+    for (; o < ms; ++o) {                                  // skip columns that end before xs
+      adj_footprint(o, m.W, ms, i0, i1, w0, w1);
+      if (i1 >= xs) break;
     }
-    csr_beg[m.W] = e;
+    ox_first[xs] = o;
+    int n = 0;
+    for (; o < ms && n < maxper; ++o, ++n) {
+      adj_footprint(o, m.W, ms, i0, i1, w0, w1);
+      if (i0 > xs) break;
+      s_wx[xs * maxper + n] = (i0 == xs ? w0 : 0.f) + (i1 == xs ? w1 : 0.f);
+    }
+    ox_cnt[xs] = n;
   }
   __syncthreads();
   // ---- phase 1
@@ -727,10 +732,10 @@ __global__ __launch_bounds__(256) void k_img_grad_level(const float* __restrict_
 #pragma unroll
   for (int k = 0; k < kAdjCols; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (cq < nc4) {
-    const int ny = s_ny;
-    for (int iy = 0; iy < ny; ++iy) {
-      const float wy = s_wy[iy];
-      const float* Gr = G + ((int64_t)(b * ms + s_oy[iy]) * ms) * Ct + coff + c0 + cq * 4;
+    const int oy1 = oy_range[1];
+    for (int oy = oy_range[0]; oy <= oy1; ++oy) {
+      const float wy = s_wy[oy];
+      const float* Gr = G + ((int64_t)(b * ms + oy) * ms) * Ct + coff + c0 + cq * 4;
 #pragma unroll
       for (int k = 0; k < kAdjCols; ++k) {
         const int ox = xl + kAdjXl * k;
@@ -748,19 +753,25 @@ __global__ __launch_bounds__(256) void k_img_grad_level(const float* __restrict_
     if (ox < ms) *(float4*)(R + ox * 64 + cq * 4) = acc[k];
   }
   __syncthreads();
-  // ---- phase 2
+  // ---- phases 2 and 3, kAdjTileW source columns at a time
   const int c = threadIdx.x & 63, xq = threadIdx.x >> 6;
-  for (int xs = xq; xs < m.W; xs += 4) {
-    float a = 0.f;
-    for (int e = csr_beg[xs]; e < csr_beg[xs + 1]; ++e) a = fmaf(csr_w[e], R[csr_ox[e] * 64 + c], a);
-    tile[c * (m.W + 1) + xs] = a;
-  }
-  __syncthreads();
-  // ---- phase 3
   float* out = const_cast<float*>(m.data) + (int64_t)b * m.sb + (int64_t)ys * m.sh;
-  for (int i = threadIdx.x; i < 64 * m.W; i += 256) {
-    const int cc = i / m.W, xs = i - cc * m.W;
-    if (c0 + cc < m.C) out[(int64_t)(c0 + cc) * m.sc + (int64_t)xs * m.sw] = tile[cc * (m.W + 1) + xs];
+  for (int x0 = 0; x0 < m.W; x0 += kAdjTileW) {
+    const int wt = min(kAdjTileW, m.W - x0);
+    for (int xs = xq; xs < wt; xs += 4) {
+      const int first = ox_first[x0 + xs], n = ox_cnt[x0 + xs];
+      const float* wx = s_wx + (x0 + xs) * maxper;
+      float a = 0.f;
+      for (int e = 0; e < n; ++e) a = fmaf(wx[e], R[(first + e) * 64 + c], a);
+      tile[c * (kAdjTileW + 1) + xs] = a;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * wt; i += 256) {
+      const int cc = i / wt, xs = i - cc * wt;
+      if (c0 + cc < m.C)
+        out[(int64_t)(c0 + cc) * m.sc + (int64_t)(x0 + xs) * m.sw] = tile[cc * (kAdjTileW + 1) + xs];
+    }
+    __syncthreads();
   }
 }
 
@@ -772,9 +783,12 @@ hipError_t launch_img_grad_to_levels(const float* grad_img_map, int B, int map_s
     const ListMap2D& m = grads[i];
     if (m.data) {
       if (m.C % 4 || coff % 4 || Ct % 4) return hipErrorInvalidValue;
-      const size_t lds = sizeof(float) * ((size_t)map_size * 64 + 64 * (size_t)(m.W + 1) + 2 * (size_t)map_size) +
-                         sizeof(int) * (2 * (size_t)map_size + (size_t)(m.W + 1) + (size_t)map_size) +
-                         sizeof(float) * (size_t)map_size;
+      // map columns per source column: ~2 / scale when up-sampling, at most a few when down-sampling
+      const float scx = map_size > 1 ? (float)(m.W - 1) / (float)(map_size - 1) : 0.f;
+      int maxper = scx > 0.f ? (int)(2.f / scx) + 4 : map_size;
+      if (maxper > map_size) maxper = map_size;
+      const size_t lds = sizeof(float) * ((size_t)map_size * 64 + 64 * (size_t)(kAdjTileW + 1) + (size_t)map_size +
+                                          (size_t)m.W * maxper) + sizeof(int) * 2 * (size_t)m.W;
       if (lds > 150 * 1024) return hipErrorInvalidValue;
       if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k_img_grad_level, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -782,7 +796,7 @@ hipError_t launch_img_grad_to_levels(const float* grad_img_map, int B, int map_s
         if (e != hipSuccess) return e;
       }
       const dim3 grid((unsigned)(B * m.H), (unsigned)((m.C + 63) / 64));
-      hipLaunchKernelGGL(k_img_grad_level, grid, dim3(256), lds, s, grad_img_map, map_size, Ct, coff, m);
+      hipLaunchKernelGGL(k_img_grad_level, grid, dim3(256), lds, s, grad_img_map, map_size, Ct, coff, m, maxper);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return e;
     }

@@ -1,10 +1,14 @@
 """Dispatch of the SDF query hot path (reference network/models.py:91-97) to the HIP library.
 
 Forward: always liblist_hip.so (..hip).  There is no CPU or PyTorch forward fallback: tensors that
-are not on a HIP device raise.  Backward ("next"): until the HIP backward kernels
-exist, gradients are obtained by re-evaluating the same mathematics with differentiable torch ops ON
-THE GPU inside a custom autograd.Function (`_recompute_with_torch_ops`); the forward values that the
-caller sees always come from the HIP kernels.
+are not on a HIP device raise.
+Backward: the fused form (LIST.forward: perceptual pooling + decoder in one call, up to
+262 144 points per call) runs list_sdf_query_bwd -- HIP kernels for the MLP weight/data gradients, the
+voxel and perceptual-map scatters, trans_mat and the adjoint resize (`_SdfQueryHipFn`).  The two
+remaining forms (pre-pooled `percep_feat`, i.e. VoxelDecoder2.forward called on its own, and queries
+above the per-call limit) obtain gradients by re-evaluating the same mathematics with differentiable
+torch ops ON THE GPU (`_SdfQueryFn`); the forward values always come from the HIP kernels.
+Query coordinates are data in the reference's training loop (train.py:82-85) and receive no gradient.
 """
 import torch
 import torch.nn.functional as F
@@ -107,6 +111,51 @@ class _SdfQueryFn(torch.autograd.Function):
         return (None, None, None, *out)
 
 
+class _SdfQueryHipFn(torch.autograd.Function):
+    """HIP forward + HIP backward.  inputs: (state, trans_mat, 5 image maps, 6 voxel maps, 8 MLP tensors)."""
+
+    @staticmethod
+    def forward(ctx, state, trans_mat, *tensors):
+        sdf, qctx = state["run"]()
+        ctx.state, ctx.qctx = state, qctx
+        ctx.trans_shape = trans_mat.shape
+        ctx.img_like = [t.detach() for t in tensors[:N_IMG]]      # shapes/strides of the encoder maps
+        ctx.mlp_shapes = [t.shape for t in tensors[N_IMG + N_VOX:]]
+        return sdf
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        needs = ctx.needs_input_grad
+        want_trans = bool(needs[1])
+        want_img = any(needs[2:2 + N_IMG])
+        want_vox = any(needs[2 + N_IMG:2 + N_IMG + N_VOX])
+        want_mlp = any(needs[2 + N_IMG + N_VOX:])
+        out = hip.sdf_query_backward(ctx.qctx, _f32(grad_out), ctx.state["packed_bwd"](), want_mlp=want_mlp,
+                                     want_img=want_img, want_vox=want_vox, want_trans=want_trans)
+        grads = [None, out["trans_mat"].reshape(ctx.trans_shape) if want_trans else None]
+        if want_img:
+            levels = hip.img_map_grad_to_levels(out["img_map"], ctx.img_like)
+            grads += [g if n else None for g, n in zip(levels, needs[2:2 + N_IMG])]
+        else:
+            grads += [None] * N_IMG
+        if want_vox:       # channels-last buffers seen as [B,C,D,H,W]
+            grads += [g.permute(0, 4, 1, 2, 3) if n else None
+                      for g, n in zip(out["vox"], needs[2 + N_IMG:2 + N_IMG + N_VOX])]
+        else:
+            grads += [None] * N_VOX
+        if want_mlp:
+            grads += [out["mlp"][k].reshape(shp) if n else None
+                      for k, shp, n in zip(MLP_KEYS, ctx.mlp_shapes, needs[2 + N_IMG + N_VOX:])]
+        else:
+            grads += [None] * len(MLP_KEYS)
+        ctx.qctx = None                    # releases the saved workspace (X, H1, H2)
+        return tuple(grads)
+
+
+HIP_BACKWARD_MAX_POINTS = 262144
+
+
 def sdf_query(query, trans_mat, img_maps, vox_maps, mlp_params, *, perm=(2, 1, 0), scale=2.0,
               map_size=137, precision="bf16x3", percep_feat=None, caches=None):
     """sdf [B,N] for raw queries; mlp_params: dict with the reference's fc_* keys."""
@@ -137,6 +186,18 @@ def sdf_query(query, trans_mat, img_maps, vox_maps, mlp_params, *, perm=(2, 1, 0
     diff = [t for t in (trans_mat, percep_feat, *img_maps, *vox_maps, *mlp)
             if t is not None and t.requires_grad]
     if torch.is_grad_enabled() and diff:
+        if percep_feat is None and query.shape[0] * query.shape[1] <= HIP_BACKWARD_MAX_POINTS \
+                and query.shape[0] * query.shape[1] > 0:
+            def run_saving():
+                return hip.sdf_query(query.detach(), trans_mat.detach(), img, vox, packed, perm=perm,
+                                     scale=scale, precision=precision, save_for_backward=True)
+
+            def packed_bwd():
+                return caches.setdefault("mlpT:" + str(precision), _Cache()).get(
+                    mlp, lambda: hip.prep_mlp_weights_bwd({k: t.detach() for k, t in zip(MLP_KEYS, mlp)},
+                                                          vox.channels, img_C, precision))
+            state = {"run": run_saving, "packed_bwd": packed_bwd}
+            return _SdfQueryHipFn.apply(state, trans_mat, *img_maps, *vox_maps, *mlp)
         if percep_feat is None:
             tensors = (*img_maps, *vox_maps, *mlp)
         else:   # keep the positional layout expected by backward
