@@ -183,6 +183,60 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
     return elapsed, kernel_ms, sdf
 
 
+def run_train_step(precision, steps, warmup, inp, hip, ev):
+    """one training step of the path = layout hand-off + weight repacks + forward (activations
+    kept) + list_sdf_query_bwd + adjoint resize, i.e. every gradient the reference's autograd produces for
+    the path (MLP parameters, 5 image maps, 6 voxel maps, trans_mat).  d(loss)/d(sdf) is synthetic."""
+    B, N = inp["B"], inp["N"]
+    md = hip.map_dtype_for(precision)
+    g = torch.Generator(device=inp["query"].device)
+    g.manual_seed(4242)
+    gsdf = torch.randn((B, N), generator=g, device=inp["query"].device) / B
+    n_ev = hip.N_BWD_STAGES
+    acc = np.zeros(n_ev - 1)
+    fwd_ms = adj_ms = 0.0
+    grads = None
+
+    def step(timed):
+        nonlocal fwd_ms, adj_ms, grads
+        arr = (ctypes.c_void_p * n_ev)(*[ev.create() for _ in range(n_ev)]) if timed else None
+        e = [ev.create() for _ in range(4)] if timed else None
+        img = hip.prep_img_maps(inp["img_maps"], inp["map_size"], md)
+        vox = hip.prep_vox_maps(inp["vox_maps"], md)
+        packed = hip.prep_mlp_weights(inp["weights"], vox.channels, img.channels, precision)
+        packed_b = hip.prep_mlp_weights_bwd(inp["weights"], vox.channels, img.channels, precision)
+        if timed: ev.record(e[0])
+        sdf, ctx = hip.sdf_query(inp["query"], inp["trans_mat"], img, vox, packed, precision=precision,
+                                 save_for_backward=True, clamp_hi=inp["clamp_hi"])
+        if timed: ev.record(e[1])
+        out = hip.sdf_query_backward(ctx, gsdf, packed_b, stage_events=arr)
+        if timed: ev.record(e[2])
+        out["img_levels"] = hip.img_map_grad_to_levels(out["img_map"], inp["img_maps"])
+        if timed: ev.record(e[3])
+        grads = out
+        return arr, e
+
+    for _ in range(warmup):
+        step(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    recs = [step(True) for _ in range(steps)]
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    for arr, e in recs:
+        for s in range(n_ev - 1):
+            acc[s] += ev.elapsed_ms(ctypes.c_void_p(arr[s]), ctypes.c_void_p(arr[s + 1]))
+        fwd_ms += ev.elapsed_ms(e[0], e[1])
+        adj_ms += ev.elapsed_ms(e[2], e[3])
+    kernel_ms = dict(zip(hip.BWD_STAGE_NAMES, (acc / steps).tolist()))
+    kernel_ms["img_grad_to_levels"] = adj_ms / steps
+    return {"precision": precision, "steps": steps, "ms_per_step": elapsed / steps * 1e3,
+            "value": B * N * steps / elapsed, "unit": "query-points/s (forward + backward)",
+            "forward_query_ms": fwd_ms / steps, "backward_ms": float(acc.sum() / steps) + adj_ms / steps,
+            "kernel_ms": kernel_ms,
+            "outputs": "d fc_0..fc_out (reference layout), d 5 image maps, d 6 voxel maps, d trans_mat"}, grads
+
+
 def roofline_of(kernel_ms, table, precision):
     """Roofline entry of the longest single kernel launch."""
     # candidates are single kernel launches; the two prep entries are groups of up to five launches
@@ -218,6 +272,7 @@ def main():
                     help="MLP arithmetic; default: headline fp16 plus a shorter bf16x3 run reported under 'alt'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-channels-last-alt", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true")
     ap.add_argument("--cpu-sample-images", type=int, default=2)
     args = ap.parse_args()
 
@@ -283,6 +338,11 @@ def main():
                "ms_per_step": a_el / a_steps * 1e3, "kernel_ms": a_ms,
                "max_abs_diff_vs_headline": float((a_sdf - sdf).abs().max())}
 
+    train = None
+    train_grads = None
+    if args.precision is None and not args.no_train_step and B * N <= 262144:
+        train, train_grads = run_train_step(headline, max(2, args.steps // 2), min(args.warmup, 2), inp, hip, ev)
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -336,6 +396,24 @@ def main():
                              f"{torch.__version__}, os.cpu_count()={os.cpu_count()}"}
             parity = float((sdf[:ns].cpu() - ref).abs().max())
             assert parity < 1e-4, f"parity bound violated: {parity}"
+            if train is not None:
+                # the same training step through torch autograd on the host (1 image), and the agreement of
+                # two gradients that depend on no ReLU mask / on every mask
+                g1 = (torch.randn((B, N), generator=torch.Generator(device=device).manual_seed(4242),
+                                  device=device) / B)[:1].cpu()
+                TO.list_query_grads(cq[:1], [m[:1] for m in ci], [m[:1] for m in cv], ct[:1], cw, g1)
+                c0 = time.perf_counter()
+                _, cg = TO.list_query_grads(cq[:1], [m[:1] for m in ci], [m[:1] for m in cv], ct[:1], cw, g1)
+                dt = time.perf_counter() - c0
+                got_T = train_grads["trans_mat"][:1].cpu()
+                got_v5 = train_grads["vox"][5][:1].permute(0, 4, 1, 2, 3).cpu()
+                train["cpu_baseline"] = {
+                    "value": N / dt, "unit": "query-points/s (forward + backward)", "cores": cores, "kind": "port",
+                    "sample": f"1 of {B} images x {N} points, torch autograd over oracle/torch_ops.py, 1 run after "
+                              "1 warm-up"}
+                train["grad_rel_l2_vs_cpu"] = {
+                    "d_trans_mat[0]": float((got_T - cg["d_trans_mat"]).norm() / cg["d_trans_mat"].norm()),
+                    "d_vox5[0]": float((got_v5 - cg["d_vox5"]).norm() / cg["d_vox5"].norm())}
 
     arith = {"bf16x3": "bf16 hi/lo split operands, 3 MFMA products per MAC, fp32 accumulate",
              "fp16": "fp16 operands (saturating), 1 MFMA product per MAC, fp32 accumulate",
@@ -365,6 +443,7 @@ def main():
         "speedup_vs_cpu": (value / cpu["value"]) if cpu else None,
         "alt": alt,
         "alt_channels_last_inputs": alt_cl,
+        "train_step": train,
     }
     print(json.dumps(out))
     if world > 1:
