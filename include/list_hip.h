@@ -257,6 +257,10 @@ typedef struct ListQueryGradArgs {
                                       /*   LIST_MAP_F32, data written through); data == NULL: skipped */
   void* workspace; size_t workspace_bytes;    /* >= list_query_bwd_workspace_bytes() */
   void* const* stage_events;          /* optional: LIST_N_BWD_STAGES hipEvent_t handles */
+  int32_t vox_adjoint;                /* how a voxel level's gradient is formed: 0 = chosen per level (LDS   */
+                                      /*   windows for coarse levels, voxel-side gather where samples are    */
+                                      /*   dense, atomics otherwise); 1 = never gather; 2 = gather wherever  */
+                                      /*   the level fits the sort's bins.  Same values up to summation order */
 } ListQueryGradArgs;
 
 enum ListBwdStage {

@@ -94,6 +94,55 @@ __device__ __forceinline__ f32x16 mfma(const bf16x8& a, const bf16x8& b, const f
 template <int FP16>
 __device__ __forceinline__ unsigned short to_half_plane(float v) { return FP16 ? f2h(v) : f2bf(v); }
 
+// ---- staged epilogue --------------------------------------------------------------------------------------
+// The MFMA accumulator layout gives a lane one COLUMN of its tile (32 lanes = 32 consecutive columns of
+// one row): storing 16-bit outputs from it means 2-byte stores in 64-B runs, 128 of them per lane, and the
+// same again for every per-element input (ReLU mask).  Instead each wave turns its 128 x 64 tile through
+// LDS, 32 rows at a time (the operand stages are dead by then), and every lane gets 8 consecutive columns
+// of a row: one 16-B load per input plane, one 16-B store per output plane, 128-B runs per row.
+constexpr int kStageLd = 68;                       // floats per staged row: 64 + 4 (row r starts 4 banks on)
+
+template <typename F>
+__device__ __forceinline__ void staged_epilogue(const f32x16 (&acc)[4][2], char* smem, int wave, int lane,
+                                                F&& emit) {
+  float* tile = (float*)smem + wave * (32 * kStageLd);
+  const int col_in = lane & 31, row_in = 4 * (lane >> 5);
+  const int rr = lane >> 3, c8 = (lane & 7) * 8;
+  __syncthreads();                                 // every wave is done with the operand stages
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        tile[((e & 3) + 8 * (e >> 2) + row_in) * kStageLd + j * 32 + col_in] = acc[i][j][e];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = rr + 8 * k;
+      const float4 a = *(const float4*)(tile + r * kStageLd + c8);
+      const float4 b = *(const float4*)(tile + r * kStageLd + c8 + 4);
+      const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      emit(i * 32 + r, c8, v);
+    }
+    __syncthreads();
+  }
+}
+
+template <int FP16>
+__device__ __forceinline__ void store8_planes(unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
+                                              int64_t off, const float (&v)[8]) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned short h0 = to_half_plane<FP16>(v[2 * e]), h1 = to_half_plane<FP16>(v[2 * e + 1]);
+    h[e] = (unsigned)h0 | ((unsigned)h1 << 16);
+    if (!FP16) l[e] = (unsigned)f2bf(v[2 * e] - bf2f(h0)) | ((unsigned)f2bf(v[2 * e + 1] - bf2f(h1)) << 16);
+  }
+  *(uint4*)(hi + off) = make_uint4(h[0], h[1], h[2], h[3]);
+  if (!FP16 && lo) *(uint4*)(lo + off) = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
 // TERMS = 3: bf16 hi/lo split (3 products); TERMS = 1: single plane, bf16 (FP16 = 0) or fp16 (FP16 = 1)
 template <int TERMS, int EPI, int FP16>
 __global__ __launch_bounds__(512, 2) void k_gemm_nt(GemmParams p) {
@@ -190,37 +239,46 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(GemmParams p) {
   const int col_in = lane & 31, row_in = 4 * (lane >> 5);
   if (EPI == EPI_MASK_SPLIT) {
     // ReLU backward: dZ_prev = acc where the saved activation is positive (network/modules.py:276-278)
-    const int64_t lane_off = (int64_t)(m0 + wm * 128 + row_in) * p.ldo + n0 + wn * 64 + col_in;
-    const int64_t mask_off = (int64_t)(m0 + wm * 128 + row_in) * p.ldmask + n0 + wn * 64 + col_in;
-    unsigned short* oh = p.out_hi + lane_off;
-    unsigned short* ol = p.out_lo ? p.out_lo + lane_off : nullptr;
-    const unsigned short* mk = p.mask + mask_off;
+    const int64_t row_base = m0 + wm * 128;
+    const int col_base = n0 + wn * 64;
+    staged_epilogue(acc, smem, wave, lane, [&](int r, int c8, const float (&v)[8]) {
+      const int64_t row = row_base + r;
+      const uint4 mk = *(const uint4*)(p.mask + row * p.ldmask + col_base + c8);
+      const unsigned mw[4] = {mk.x, mk.y, mk.z, mk.w};
+      float o[8];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int r = i * 32 + (e & 3) + 8 * (e >> 2);
-          const float v = (mk[r * p.ldmask + j * 32] & 0x7fff) ? acc[i][j][e] : 0.f;
-          const unsigned short h = to_half_plane<FP16>(v);
-          oh[r * p.ldo + j * 32] = h;
-          if (!FP16 && ol) ol[r * p.ldo + j * 32] = f2bf(v - bf2f(h));
-        }
+      for (int e = 0; e < 4; ++e) {
+        o[2 * e] = (mw[e] & 0x7fffu) ? v[2 * e] : 0.f;
+        o[2 * e + 1] = (mw[e] & 0x7fff0000u) ? v[2 * e + 1] : 0.f;
+      }
+      store8_planes<FP16>(p.out_hi, p.out_lo, row * p.ldo + col_base + c8, o);
+    });
   } else if (EPI == EPI_DX) {
-    const int64_t lane_off = (int64_t)(m0 + wm * 128 + row_in) * p.ldo + n0 + wn * 64 + col_in;
+    const int64_t row_base = m0 + wm * 128;
+    const int col_base = n0 + wn * 64;
+    staged_epilogue(acc, smem, wave, lane, [&](int r, int c8, const float (&v)[8]) {
+      if (col_base + c8 >= p.n_store) return;                  // n_store is a multiple of 8
+      const int64_t off = (row_base + r) * p.ldo + col_base + c8;
+      if (p.dx_f16) {
+        const uint2 a = half4(make_float4(v[0], v[1], v[2], v[3])), b = half4(make_float4(v[4], v[5], v[6], v[7]));
+        *(uint4*)((unsigned short*)p.dx + off) = make_uint4(a.x, a.y, b.x, b.y);
+      } else {
+        *(float4*)((float*)p.dx + off) = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)((float*)p.dx + off + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+    });
+  } else if (EPI == EPI_RELU_SPLIT) {
+    const int64_t row_base = m0 + wm * 128;
+    const int col_base = n0 + wn * 64;
+    staged_epilogue(acc, smem, wave, lane, [&](int r, int c8, const float (&v)[8]) {
+      float o[8];
+      const float4 b0 = p.bias ? *(const float4*)(p.bias + col_base + c8) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 b1 = p.bias ? *(const float4*)(p.bias + col_base + c8 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (n0 + wn * 64 + j * 32 + col_in >= p.n_store) continue;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int64_t off = lane_off + (int64_t)(i * 32 + (e & 3) + 8 * (e >> 2)) * p.ldo + j * 32;
-          if (p.dx_f16) ((unsigned short*)p.dx)[off] = f2h(acc[i][j][e]);
-          else ((float*)p.dx)[off] = acc[i][j][e];
-        }
-    }
+      for (int e = 0; e < 8; ++e) o[e] = fmaxf(v[e] + bb[e], 0.f);
+      store8_planes<FP16>(p.out_hi, p.out_lo, (row_base + r) * p.ldo + col_base + c8, o);
+    });
   } else if (EPI == EPI_RELU_SPLIT || EPI == EPI_F32) {
     // one base pointer per output plane; per-element offsets are (wave-uniform row term) + lane term
     const int ld = EPI == EPI_F32 ? p.N : p.ldo;

@@ -419,6 +419,7 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
     return fail(LIST_ERR_UNSUPPORTED, "backward supports hidden sizes up to 2048 (got %d/%d)", a->H1, a->H2);
   if (a->precision < LIST_PREC_BF16X3 || a->precision > LIST_PREC_FP16)
     return fail(LIST_ERR_ARG, "precision=%d", a->precision);
+  if (ga->vox_adjoint < 0 || ga->vox_adjoint > 2) return fail(LIST_ERR_ARG, "vox_adjoint=%d", ga->vox_adjoint);
   const int64_t P = (int64_t)a->B * a->N;
   if (P > kMaxChunkRows)
     return fail(LIST_ERR_UNSUPPORTED, "backward handles up to %lld points per call (got %lld)",
@@ -566,7 +567,10 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   const bool pix = !a->no_sort && a->map_size * ((a->map_size + 3) / 4) <= kSortPixCells;
   if (pix) { sp.g.order_img = (const int*)(fw + ws.order_img); sp.g.row_of = (const int*)(fw + ws.row_of); }
   sp.dx = bwp + bw.dx; sp.dx_f16 = fp16 ? 1 : 0; sp.scale = scale;
-  LIST_TRY(launch_scatter_vox(sp, L, *a, ga->grad_vox, s), "voxel scatter launch");
+  VoxGatherBuffers vb;
+  vb.keys = (int*)(bwp + bw.vs_keys); vb.bins = (int*)(bwp + bw.vs_bins); vb.sums = (int*)(bwp + bw.vs_sums);
+  vb.recs = bwp + bw.vs_recs; vb.mode = ga->vox_adjoint;
+  LIST_TRY(launch_scatter_vox(sp, L, *a, ga->grad_vox, vb, s), "voxel scatter launch");
   mark(LIST_BWD_VOX);
   const int nslots = a->B < kSortImages ? a->B : kSortImages;
   const int* bins_pix = pix ? (const int*)(fw + ws.bins) + (size_t)nslots * kSortCells : nullptr;

@@ -192,6 +192,9 @@ inline PackedMlpBwd packed_mlp_bwd_layout(int Kp, int H1, int H2, int H3) {
 }
 
 // ---- backward workspace -----------------------------------------------------------------------------------
+#ifndef LIST_VOX_GATHER_MIN_DENSITY
+#define LIST_VOX_GATHER_MIN_DENSITY 2.0
+#endif
 constexpr int kColsumRows = 256;         // rows per partial of the bias-gradient column sums
 constexpr int kWgradMaxSplits = 128;
 
@@ -203,6 +206,7 @@ struct BwdWorkspace {
   size_t slab;                               // wgrad partials, fp32
   size_t colsum;                             // bias-gradient partials
   size_t recs;                               // per-point projection records (2-D gradient)
+  size_t vs_keys, vs_bins, vs_sums, vs_recs; // voxel-side gather: sample keys, cell counters, scan sums, records
   size_t total;
 };
 inline int wgrad_nominal_splits(int M, int N) {     // enough workgroups to fill 256 CUs twice
@@ -232,6 +236,10 @@ inline BwdWorkspace bwd_workspace_layout(int64_t rows, int Kp, int H1, int H2, i
   const int hmax = H1 > H2 ? (H1 > H3 ? H1 : H3) : (H2 > H3 ? H2 : H3);
   w.colsum = take((size_t)((rows + kColsumRows - 1) / kColsumRows) * hmax * 4);
   w.recs = take((size_t)rows * 32);
+  w.vs_keys = take((size_t)rows * 8 * 4);
+  w.vs_bins = take((size_t)4194304 * 4);
+  w.vs_sums = take(1024 * 4);
+  w.vs_recs = take((size_t)rows * LIST_N_STENCIL * 16);
   w.total = o;
   return w;
 }
@@ -356,8 +364,13 @@ struct ScatterParams {
   const void* dx; int dx_f16; // [rows][Kp]
   const float* scale;         // [0] = s, [1] = 1/s
 };
+// buffers of the voxel-side gather (bwd_scatter_kernels.hip); bins == nullptr disables it
+constexpr int64_t kVoxGatherMaxBins = 4194304;      // cells (B * D * H * W) a level may have
+constexpr double kVoxGatherMinDensity = LIST_VOX_GATHER_MIN_DENSITY;   // samples per cell
+struct VoxGatherBuffers { int* keys; int* bins; int* sums; void* recs; int mode; };   // mode: ListQueryGradArgs.vox_adjoint
 hipError_t launch_scatter_vox(const ScatterParams& sp, const FeatLayout& L, const ListQueryArgs& a,
-                              const ListVoxLevel grad_vox[LIST_N_VOX_LEVELS], hipStream_t s);
+                              const ListVoxLevel grad_vox[LIST_N_VOX_LEVELS], const VoxGatherBuffers& vb,
+                              hipStream_t s);
 hipError_t launch_img_grad(const ScatterParams& sp, const FeatLayout& L, const ListQueryArgs& a,
                            const int* bins_pix, int nslots, void* recs, float* grad_img_map,
                            float* grad_trans_mat, void* const* stage_events, hipStream_t s);

@@ -82,9 +82,10 @@ class ListQueryGradArgs(C.Structure):
                 ("grad_img_map", C.c_void_p), ("grad_trans_mat", C.c_void_p),
                 ("grad_vox", ListVoxLevel * N_VOX_LEVELS),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-                ("stage_events", C.POINTER(C.c_void_p))]
+                ("stage_events", C.POINTER(C.c_void_p)), ("vox_adjoint", C.c_int32)]
 
 
+VOX_ADJOINT = {"auto": 0, "scatter": 1, "gather": 2}
 N_BWD_STAGES = 11
 BWD_STAGE_NAMES = ("head", "wgrad_fc2", "dgrad_fc2", "wgrad_fc1", "dgrad_fc1", "wgrad_fc0", "dgrad_fc0",
                    "scatter_vox", "img_map_grad", "trans_mat_grad")
@@ -413,7 +414,7 @@ def sdf_query(query, trans_mat, img, vox, packed, perm=(2, 1, 0), scale=2.0, pre
 
 
 def sdf_query_backward(ctx, grad_sdf, packed_bwd, want_mlp=True, want_img=True, want_vox=True,
-                       want_trans=True, stage_events=None):
+                       want_trans=True, stage_events=None, vox_adjoint="auto"):
     """Backward of sdf_query (list_sdf_query_bwd).  Returns a dict:
       'mlp'       : {fc_0.weight [H1,F,1], fc_0.bias, ..., fc_out.bias} (reference layouts)
       'img_map'   : gradient of the prepared perceptual map, float32 [B,ms,ms,Ct]
@@ -428,6 +429,7 @@ def sdf_query_backward(ctx, grad_sdf, packed_bwd, want_mlp=True, want_img=True, 
     ga.fwd = C.pointer(a)
     ga.grad_sdf = g.data_ptr()
     ga.packed_mlp_bwd = packed_bwd.data_ptr()
+    ga.vox_adjoint = VOX_ADJOINT[vox_adjoint]
     out = {}
     f32 = dict(dtype=torch.float32, device=dev)
     if want_mlp:

@@ -181,6 +181,21 @@ def test_backward_on_the_real_map_sizes_against_the_oracle(hip):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("name", ["gsmall", "gtiny"])
+def test_voxel_adjoint_forms_agree_with_the_reference(hip, golden_dir, name):
+    """The three ways a voxel level's gradient is formed (global atomics, LDS windows, voxel-side gather)
+    are chosen per level by size; forcing the gather everywhere / nowhere must give the reference's values."""
+    g = np.load(os.path.join(golden_dir, f"hotpath_grad_{name}.npz"))
+    c = cases.build_case(name)
+    for mode in ("gather", "scatter"):
+        _, got = hip_gradients(hip, c, g["grad_sdf"], "bf16x3",
+                               want=dict(want_mlp=False, want_img=False, want_trans=False, vox_adjoint=mode))
+        for i in range(6):
+            k = f"d_vox{i}"
+            a = slice_like_golden(name, k, got[k])
+            assert rel_max(a, g[k]) < TOL_X3_RELMAX, (mode, k, rel_max(a, g[k]))
+
+
 def test_backward_large_batch_statistics(hip):
     """B = 8 x 6000 points (several Morton runs per voxel, many workgroups per image, rows padded): the
     HIP gradients in fp16 against the HIP gradients in bf16x3 (same kernels, 2-4 % mask-flip noise), and
