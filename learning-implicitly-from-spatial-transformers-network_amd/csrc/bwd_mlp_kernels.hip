@@ -132,31 +132,39 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn(GemmTnParams p) {
     if (t + 1 < t1)
       stage_tn<TERMS>(p, smem + ((t + 1 - t0) & 1) * P::kStageBytes, (int64_t)(t + 1) * P::BK, m0, n0, wave, lane);
     const char* cur = smem + ((t - t0) & 1) * P::kStageBytes;
-#pragma unroll
-    for (int s2 = 0; s2 < P::BK / 16; ++s2) {
+    // register double-buffered fragments: the transposed reads of k16-step s2+1 are issued ahead of the
+    // MFMAs of step s2 (same scheme as k_gemm_nt)
+    constexpr int NS = P::BK / 16;
+    s16x8 ah[2][4], al[2][4], bh[2][2], bl[2][2];
+    auto load_frags = [&](int s2, int buf) {
       const char* cs = cur + s2 * 16 * P::kRowBytes;
-      s16x8 ah[4], al[4], bh[2], bl[2];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        ah[i] = cat4(tr_read(cs + a_off[0][i]), tr_read(cs + a_off[1][i]));
+        ah[buf][i] = cat4(tr_read(cs + a_off[0][i]), tr_read(cs + a_off[1][i]));
         if (TERMS == 3)
-          al[i] = cat4(tr_read(cs + P::kPlaneBytes + a_off[0][i]), tr_read(cs + P::kPlaneBytes + a_off[1][i]));
+          al[buf][i] = cat4(tr_read(cs + P::kPlaneBytes + a_off[0][i]), tr_read(cs + P::kPlaneBytes + a_off[1][i]));
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        bh[j] = cat4(tr_read(cs + b_off[0][j]), tr_read(cs + b_off[1][j]));
+        bh[buf][j] = cat4(tr_read(cs + b_off[0][j]), tr_read(cs + b_off[1][j]));
         if (TERMS == 3)
-          bl[j] = cat4(tr_read(cs + P::kPlaneBytes + b_off[0][j]), tr_read(cs + P::kPlaneBytes + b_off[1][j]));
+          bl[buf][j] = cat4(tr_read(cs + P::kPlaneBytes + b_off[0][j]), tr_read(cs + P::kPlaneBytes + b_off[1][j]));
       }
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) {
+      const int bb = s2 & 1;
+      if (s2 + 1 < NS) load_frags(s2 + 1, bb ^ 1);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           if (TERMS == 3) {
-            acc[i][j] = mfma_tn<0>(al[i], bh[j], acc[i][j]);
-            acc[i][j] = mfma_tn<0>(ah[i], bl[j], acc[i][j]);
+            acc[i][j] = mfma_tn<0>(al[bb][i], bh[bb][j], acc[i][j]);
+            acc[i][j] = mfma_tn<0>(ah[bb][i], bl[bb][j], acc[i][j]);
           }
-          acc[i][j] = mfma_tn<FP16>(ah[i], bh[j], acc[i][j]);
+          acc[i][j] = mfma_tn<FP16>(ah[bb][i], bh[bb][j], acc[i][j]);
         }
     }
   }

@@ -76,26 +76,78 @@ __global__ __launch_bounds__(256) void k_scatter_vox(ScatterParams sp, ListVoxLe
 // The workgroup's 64 points are cut into runs adaptively: 8-point boxes are merged greedily while the
 // merged box fits the window (8^3 level: ~32 points per run, 16^3: ~16); a box that does not fit on its
 // own goes straight to memory.
-constexpr int kWinFloats = 18432;          // 72 KB window: two workgroups per CU
-constexpr int kSubPts = 8;                 // granularity of the run planner = points per tap-record chunk
+constexpr int kSubPts = 8;                 // granularity of the run planner = points per record chunk
 constexpr int kNSub = kScatterRows / kSubPts;
-struct TapRec { int o[8]; float w[8]; };
 struct Run { int first, count, direct; int ox, oy, oz, nx, ny, nz, b; };
 
-template <int C, int DXH>
+// All 7 stencil samples of a point lie within the 4 x 4 x 4 voxels around the centre's cell when the
+// stencil is shorter than a voxel, and they touch only 32 of them (the "plus" the forward's
+// k_gather_vox_near reads): 4 x-slots x the centre's 2x2 in (y,z), plus 2 extra y-slots and 2 extra
+// z-slots over the centre's 2x2 of the other axes.  The adjoint per point is therefore ONE batch of 32
+// read-add-writes with the per-axis 4-slot weight vectors of the centre / minus / plus samples:
+//   X[k] = g0 wcx[k] + g1 wmx[k] + g2 wpx[k],  Y[k] = g3 wmy[k] + g4 wpy[k],  Z[k] = g5 wmz[k] + g6 wpz[k]
+//   dV[kx][ky][kz] = X[kx] wcy[ky] wcz[kz] + wcx[kx] Y[ky] wcz[kz] + wcx[kx] wcy[ky] Z[kz]
+struct NearRec { int o[32]; float wx[3][4], wy[3][4], wz[3][4]; };
+
+__device__ __forceinline__ void slot_weights(const Axis& a, int cbase, float (&w)[4], bool (&used)[4]) {
+  const int k0 = a.i0 - cbase;            // 0, 1 or 2
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool lo = k == k0, hi = (k == k0 + 1) && a.has1;
+    w[k] = lo ? a.w0 : (hi ? a.w1 : 0.f);
+    used[k] = used[k] || lo || hi;
+  }
+}
+
+__device__ __forceinline__ void build_near(const Pt& p, int W, int H, int D, const Run& r, int C, NearRec& n) {
+  const float pc[3] = {p.x, p.y, p.z};
+  const int S[3] = {W, H, D};
+  int base[3];
+  bool used[3][4];
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+    const Axis c = axis_setup(pc[ax], S[ax]), m = axis_setup(pc[ax] - kDisp, S[ax]), q = axis_setup(pc[ax] + kDisp, S[ax]);
+    base[ax] = c.i0 - 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) used[ax][k] = false;
+    float(*w)[4] = ax == 0 ? n.wx : (ax == 1 ? n.wy : n.wz);
+    slot_weights(c, base[ax], w[0], used[ax]);
+    slot_weights(m, base[ax], w[1], used[ax]);
+    slot_weights(q, base[ax], w[2], used[ax]);
+  }
+  const int vol = r.nx * r.ny * r.nz;
+  auto cell = [&](int kx, int ky, int kz) -> int {
+    if (!p.valid || !used[0][kx] || !used[1][ky] || !used[2][kz]) return vol * C;      // dummy cell
+    return (((base[2] + kz - r.oz) * r.ny + (base[1] + ky - r.oy)) * r.nx + (base[0] + kx - r.ox)) * C;
+  };
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) n.o[k * 4 + q] = cell(k, 1 + (q & 1), 1 + (q >> 1));
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      n.o[16 + e * 4 + q] = cell(1 + (q & 1), e ? 3 : 0, 1 + (q >> 1));
+      n.o[24 + e * 4 + q] = cell(1 + (q & 1), 1 + (q >> 1), e ? 3 : 0);
+    }
+}
+
+// kWinFloats: 18432 (72 KB, two workgroups per CU) for the 16^3 level, whose runs need ~100-voxel boxes;
+// 9216 (36 KB, four per CU) for the 8^3 level
+template <int C, int DXH, int kWinFloats>
 __global__ __launch_bounds__((C >= 128 ? C : 128)) void k_scatter_vox_win(ScatterParams sp, ListVoxLevel gv,
                                                                              int col_off) {
   constexpr int T = C >= 128 ? C : 128;
   constexpr int COPIES = T / C;
   constexpr int MYP = kSubPts / COPIES;              // points per copy per chunk
   constexpr int kCap = kWinFloats / T - 1;           // window voxels (one more cell is the dummy)
-  static_assert(C >= 16 && T % C == 0 && kSubPts % COPIES == 0 && T >= kScatterRows &&
-                T >= kSubPts * LIST_N_STENCIL, "geometry");
+  static_assert(C >= 16 && T % C == 0 && kSubPts % COPIES == 0 && T >= kScatterRows, "geometry");
   __shared__ Pt pts[kScatterRows];
   __shared__ int box[kNSub][8];                      // lo x,y,z | hi x,y,z | min image | max image
   __shared__ Run runs[kNSub];
   __shared__ int n_runs;
-  __shared__ TapRec taps[kSubPts * LIST_N_STENCIL];
+  __shared__ NearRec nrec[kSubPts];
   __shared__ float win[kWinFloats];
   const int tid = threadIdx.x;
   const int c = tid % C, k = tid / C;
@@ -158,25 +210,8 @@ __global__ __launch_bounds__((C >= 128 ? C : 128)) void k_scatter_vox_win(Scatte
     for (int v = 0; v <= vol; ++v) mine[v * C] = 0.f;
 #pragma unroll 1
     for (int ch = 0; ch < r.count; ch += kSubPts) {
-      __syncthreads();                               // previous chunk's tap records are consumed
-      if (tid < kSubPts * LIST_N_STENCIL) {
-        const int pl = tid / LIST_N_STENCIL, j = tid - pl * LIST_N_STENCIL;
-        const Pt p = pts[r.first + ch + pl];
-        float x, y, z;
-        stencil_rt(p, j, x, y, z);
-        const Axis ax = axis_setup(x, W), ay = axis_setup(y, H), az = axis_setup(z, D);
-        const int o000 = ((az.i0 - r.oz) * ny + (ay.i0 - r.oy)) * nx + (ax.i0 - r.ox);
-        TapRec t;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const bool ux = q & 1, uy = q & 2, uz = q & 4;
-          const bool off = (ux && !ax.has1) || (uy && !ay.has1) || (uz && !az.has1) || !p.valid;
-          const float w = (ux ? ax.w1 : ax.w0) * (uy ? ay.w1 : ay.w0) * (uz ? az.w1 : az.w0);
-          t.o[q] = off ? vol * C : (o000 + (ux ? 1 : 0) + (uy ? nx : 0) + (uz ? nx * ny : 0)) * C;
-          t.w[q] = off ? 0.f : w;
-        }
-        taps[tid] = t;
-      }
+      __syncthreads();                               // previous chunk's records are consumed
+      if (tid < kSubPts) build_near(pts[r.first + ch + tid], W, H, D, r, C, nrec[tid]);
       // my points of the chunk: every dX value is requested before the first use
       float gval[MYP][LIST_N_STENCIL];
 #pragma unroll
@@ -187,16 +222,39 @@ __global__ __launch_bounds__((C >= 128 ? C : 128)) void k_scatter_vox_win(Scatte
       }
       __syncthreads();
 #pragma unroll
-      for (int m = 0; m < MYP; ++m)
+      for (int m = 0; m < MYP; ++m) {                // (unrolled: gval[m] must stay in registers)
+        const NearRec& n = nrec[k + COPIES * m];
+        const float* g = gval[m];
+        float X[4], Y[4], Z[4];
 #pragma unroll
-        for (int j = 0; j < LIST_N_STENCIL; ++j) {
-          const TapRec& t = taps[(k + COPIES * m) * LIST_N_STENCIL + j];
-          float v[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] = mine[t.o[q]];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) mine[t.o[q]] = fmaf(t.w[q], gval[m][j], v[q]);
+        for (int q = 0; q < 4; ++q) {
+          X[q] = fmaf(g[2], n.wx[2][q], fmaf(g[1], n.wx[1][q], g[0] * n.wx[0][q]));
+          Y[q] = fmaf(g[4], n.wy[2][q], g[3] * n.wy[1][q]);
+          Z[q] = fmaf(g[6], n.wz[2][q], g[5] * n.wz[1][q]);
         }
+        float G[32];
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int ky = 1 + (q & 1), kz = 1 + (q >> 1);
+            G[kx * 4 + q] = fmaf(X[kx], n.wy[0][ky] * n.wz[0][kz],
+                                 n.wx[0][kx] * fmaf(Y[ky], n.wz[0][kz], n.wy[0][ky] * Z[kz]));
+          }
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int ka = 1 + (q & 1), kb = 1 + (q >> 1), ke = e ? 3 : 0;
+            G[16 + e * 4 + q] = n.wx[0][ka] * Y[ke] * n.wz[0][kb];
+            G[24 + e * 4 + q] = n.wx[0][ka] * n.wy[0][kb] * Z[ke];
+          }
+        float v[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) v[q] = mine[n.o[q]];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) mine[n.o[q]] = v[q] + G[q];
+      }
     }
     __syncthreads();
     float* base = gout + (int64_t)r.b * gv.image_stride;
@@ -313,17 +371,23 @@ __global__ __launch_bounds__(256) void k_vs_gather(ScatterParams sp, ListVoxLeve
   const int x = (int)(vox % W), y = (int)((vox / W) % H), z = (int)((vox / ((int64_t)W * H)) % D);
   const int b = (int)(vox / ((int64_t)W * H * D));
   float acc = 0.f;
-#pragma unroll 1
+  // the record ranges of the four (y, z) lines first (12 independent loads), then the samples
+  int r_lo[4], r_mid[4], r_hi[4];
+#pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int dy = q & 1, dz = q >> 1;
-    const int yy = y - dy, zz = z - dz;
+    const int yy = y - (q & 1), zz = z - (q >> 1);
+    r_lo[q] = r_mid[q] = r_hi[q] = 0;
     if (yy < 0 || zz < 0) continue;
     // cells x-1 and x of this (y, z) line are adjacent bins: one contiguous run of records
-    const int base = ((b * D + zz) * H + yy) * W;
-    const int bin1 = base + x;                               // cell x     (corner dx = 0)
-    const int s_mid = bin1 > 0 ? ends[bin1 - 1] : 0;         // = end of cell x-1
-    const int s_lo = x > 0 ? (bin1 > 1 ? ends[bin1 - 2] : 0) : s_mid;
-    const int s_hi = ends[bin1];
+    const int bin1 = ((b * D + zz) * H + yy) * W + x;          // cell x (corner dx = 0)
+    r_mid[q] = bin1 > 0 ? ends[bin1 - 1] : 0;                  // = end of cell x-1
+    r_lo[q] = x > 0 ? (bin1 > 1 ? ends[bin1 - 2] : 0) : r_mid[q];
+    r_hi[q] = ends[bin1];
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int dy = q & 1, dz = q >> 1;
+    const int s_lo = r_lo[q], s_mid = r_mid[q], s_hi = r_hi[q];
     for (int s = s_lo; s < s_hi; s += NB) {
       VoxSample r[NB];
 #pragma unroll
@@ -388,8 +452,13 @@ static hipError_t scatter_level(const ScatterParams& sp, const ListVoxLevel& gv,
   if constexpr (C >= 64) {
     if (reach < 0.99f) {
       constexpr int T = C >= 128 ? C : 128;
-      if (sp.dx_f16) hipLaunchKernelGGL((k_scatter_vox_win<C, 1>), grid, dim3(T), 0, s, sp, gv, col_off);
-      else hipLaunchKernelGGL((k_scatter_vox_win<C, 0>), grid, dim3(T), 0, s, sp, gv, col_off);
+      if (reach < 0.34f) {          // 8^3: small boxes, four workgroups per CU
+        if (sp.dx_f16) hipLaunchKernelGGL((k_scatter_vox_win<C, 1, 9216>), grid, dim3(T), 0, s, sp, gv, col_off);
+        else hipLaunchKernelGGL((k_scatter_vox_win<C, 0, 9216>), grid, dim3(T), 0, s, sp, gv, col_off);
+      } else {
+        if (sp.dx_f16) hipLaunchKernelGGL((k_scatter_vox_win<C, 1, 18432>), grid, dim3(T), 0, s, sp, gv, col_off);
+        else hipLaunchKernelGGL((k_scatter_vox_win<C, 0, 18432>), grid, dim3(T), 0, s, sp, gv, col_off);
+      }
       return hipGetLastError();
     }
   }
