@@ -57,7 +57,8 @@ def list_query(query, img_maps, vox_maps, trans_mat, weights, pre_permuted=False
     return implicit_mlp(feats, weights)
 
 
-def list_query_grads(query, img_maps, vox_maps, trans_mat, weights, grad_sdf, pre_permuted=False):
+def list_query_grads(query, img_maps, vox_maps, trans_mat, weights, grad_sdf, pre_permuted=False,
+                     map_size=137):
     """Backward of the path by autograd over the same op sequence (the reference trains through
     exactly these ops, train.py:82-85): gradients of sum(sdf * grad_sdf) w.r.t. the 2-D maps, the 3-D
     maps, trans_mat and the MLP parameters.  Returns (sdf, dict)."""
@@ -68,7 +69,7 @@ def list_query_grads(query, img_maps, vox_maps, trans_mat, weights, grad_sdf, pr
         T = leaf(trans_mat)
         W = {k: leaf(v) for k, v in weights.items()}
         pts = query if pre_permuted else query[:, :, [2, 1, 0]] * 2
-        percep = pooled_image_features(img_l, pts, T)
+        percep = pooled_image_features(img_l, pts, T, map_size)
         feats = torch.cat((stencil_voxel_features(pts, vox_l), percep, pts.transpose(1, 2)), dim=1)
         sdf = implicit_mlp(feats, W)
         (sdf * grad_sdf).sum().backward()
