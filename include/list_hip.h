@@ -228,8 +228,9 @@ int list_to_fp16(const float* x, void* out, int64_t n, void* stream);
  * Contract with the forward: `fwd` are the arguments of a list_sdf_query_fwd call that has been
  * enqueued before on the same stream, with fwd->workspace UNTOUCHED since (it holds the feature
  * matrix, the hidden activations and the point order), and the whole query in ONE row chunk
- * (B*N <= 262144 and workspace_bytes >= list_query_workspace_bytes(B*N)).  fwd->percep_feat must be
- * NULL (the fused form).  Arithmetic follows fwd->precision: BF16X3 keeps every gradient operand as
+ * (B*N <= 262144 and workspace_bytes >= list_query_workspace_bytes(B*N)).  With fwd->percep_feat (the
+ * pre-pooled form) the perceptual part of the gradient is returned as grad_percep_feat instead of
+ * grad_img_map / grad_trans_mat (list_percep_pool_bwd takes it from there).  Arithmetic follows fwd->precision: BF16X3 keeps every gradient operand as
  * bf16 hi+lo (fp32-grade), FP16 scales d(sdf) by a power of two into the fp16 range (undone in the
  * fp32 epilogues), BF16 rounds gradient operands to bf16.  All sums are fp32.
  * Outputs are OVERWRITTEN (not accumulated); a NULL output is skipped.  Map and trans_mat
@@ -261,6 +262,8 @@ typedef struct ListQueryGradArgs {
                                       /*   windows for coarse levels, voxel-side gather where samples are    */
                                       /*   dense, atomics otherwise); 1 = never gather; 2 = gather wherever  */
                                       /*   the level fits the sort's bins.  Same values up to summation order */
+  float* grad_percep_feat;            /* only with fwd->percep_feat (VoxelDecoder2.forward's own form): the    */
+  int64_t gpf_sb, gpf_sc, gpf_sn;     /*   gradient of the pre-pooled features, [B,img_C,N] with these strides */
 } ListQueryGradArgs;
 
 enum ListBwdStage {
@@ -289,6 +292,22 @@ int list_sdf_query_bwd(const ListQueryGradArgs* args, void* stream);
  * through the given strides, every element overwritten) must describe [B,C_i,H_i,W_i]. */
 int list_img_map_grad_to_levels(const float* grad_img_map, int32_t B, int32_t map_size,
                                 const ListMap2D grads[LIST_N_IMG_LEVELS], void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * list_percep_pool_bwd -- backward of list_percep_pool_fwd (PerceptualPooling.forward on its own,
+ * network/modules.py:37-53): d(loss)/d(out [B,img_C,N]) -> gradient of the prepared map and of trans_mat.
+ * (The stand-alone form has no point sort, so the map gradient is accumulated with fp32 atomics; the fused
+ * list_sdf_query_bwd is the fast path.)  Outputs are overwritten; NULL outputs are skipped.
+ */
+typedef struct ListPoolGradArgs {
+  const ListPoolArgs* fwd;                       /* pc, trans_mat, img_map, ... of the forward call (out unused) */
+  const float* grad_out; int64_t g_sb, g_sc, g_sn;   /* [B,img_C,N] with element strides */
+  float* grad_img_map;                           /* [B][map_size][map_size][img_C] fp32, or NULL */
+  float* grad_trans_mat;                         /* [B,4,3], or NULL */
+  void* workspace; size_t workspace_bytes;       /* >= list_percep_pool_bwd_workspace_bytes(B*N, img_C) */
+} ListPoolGradArgs;
+size_t list_percep_pool_bwd_workspace_bytes(int64_t n_points, int32_t img_C);
+int list_percep_pool_bwd(const ListPoolGradArgs* args, void* stream);
 
 /* list_gemm_tn -- test/diagnostic entry for the transposed-operand MFMA kernel of the weight
  * gradients: out[M][N] = sum_p A[p][m] * B[p][n], A [P][M] and B [P][N] given as 16-bit planes like

@@ -1015,6 +1015,89 @@ __global__ __launch_bounds__(256) void k_img_grad_level(const float* __restrict_
   }
 }
 
+// ---- pre-pooled form: [B][C][N] <-> rows --------------------------------------------------------------------
+// out[b][c][n] = (1/s) dX[row of point (b,n)][img_off + c]: the gradient of VoxelDecoder2.forward's third
+// argument.  64 points x 64 channels per workgroup, turned through LDS so reads run along c, writes along n.
+template <int DXH>
+__global__ __launch_bounds__(256) void k_rows_to_grad(const void* __restrict__ dx, int Kp, int img_off,
+                                                      const int* __restrict__ row_of, float* __restrict__ out,
+                                                      int64_t sb, int64_t sc, int64_t sn, int N, int C,
+                                                      const float* __restrict__ scale) {
+  __shared__ float tile[64][65];
+  const int nt = (N + 63) / 64;
+  const int b = blockIdx.x / nt, n0 = (blockIdx.x % nt) * 64, c0 = blockIdx.y * 64;
+  const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+  for (int i = q; i < 64; i += 4) {
+    const int n = n0 + i;
+    float v = 0.f;
+    if (n < N && c0 + cl < C) {
+      const int pt = b * N + n;
+      const int row = row_of ? row_of[pt] : pt;
+      v = dx_at<DXH>(dx, (int64_t)row * Kp + img_off + c0 + cl);
+    }
+    tile[i][cl] = v;
+  }
+  __syncthreads();
+  const float inv_s = scale[1];
+  for (int i = q; i < 64; i += 4) {
+    const int c = c0 + i, n = n0 + cl;
+    if (c < C && n < N) out[(int64_t)b * sb + (int64_t)c * sc + (int64_t)n * sn] = tile[cl][i] * inv_s;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_invert_order(const int* __restrict__ order, int n, int* __restrict__ row_of) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r < n) row_of[order[r]] = r;
+}
+
+hipError_t launch_rows_to_grad(const ScatterParams& sp, int img_off, int C, int B, int* row_of_scratch, float* out,
+                               int64_t sb, int64_t sc, int64_t sn, hipStream_t s) {
+  const int* row_of = nullptr;
+  if (sp.g.order) {
+    hipLaunchKernelGGL(k_invert_order, dim3((unsigned)((sp.g.n_valid + 255) / 256)), dim3(256), 0, s, sp.g.order,
+                       sp.g.n_valid, row_of_scratch);
+    row_of = row_of_scratch;
+  }
+  const dim3 grid((unsigned)(B * ((sp.g.N + 63) / 64)), (unsigned)((C + 63) / 64));
+  if (sp.dx_f16)
+    hipLaunchKernelGGL(k_rows_to_grad<1>, grid, dim3(256), 0, s, sp.dx, sp.g.Kp, img_off, row_of, out, sb, sc, sn, sp.g.N,
+                       C, sp.scale);
+  else
+    hipLaunchKernelGGL(k_rows_to_grad<0>, grid, dim3(256), 0, s, sp.dx, sp.g.Kp, img_off, row_of, out, sb, sc, sn, sp.g.N,
+                       C, sp.scale);
+  return hipGetLastError();
+}
+
+// dx[b*N + n][c] = src[b][c][n], rows beyond B*N zero; scale = {1, 1}
+__global__ __launch_bounds__(256) void k_grad_to_rows(const float* __restrict__ src, int64_t sb, int64_t sc, int64_t sn,
+                                                      int N, int C, float* __restrict__ dx) {
+  __shared__ float tile[64][65];
+  const int nt = (N + 63) / 64;
+  const int b = blockIdx.x / nt, n0 = (blockIdx.x % nt) * 64, c0 = blockIdx.y * 64;
+  const int l = threadIdx.x & 63, q = threadIdx.x >> 6;
+  for (int i = q; i < 64; i += 4) {
+    const int c = c0 + i, n = n0 + l;
+    tile[i][l] = (c < C && n < N) ? src[(int64_t)b * sb + (int64_t)c * sc + (int64_t)n * sn] : 0.f;
+  }
+  __syncthreads();
+  for (int i = q; i < 64; i += 4) {
+    const int n = n0 + i, c = c0 + l;
+    if (n < N && c < C) dx[((int64_t)b * N + n) * C + c] = tile[l][i];
+  }
+}
+
+__global__ void k_unit_scale(float* scale) {
+  if (threadIdx.x < 4) scale[threadIdx.x] = threadIdx.x < 2 ? 1.f : 0.f;
+}
+
+hipError_t launch_grad_to_rows(const float* src, int64_t sb, int64_t sc, int64_t sn, int B, int N, int C, float* dx,
+                               float* scale, hipStream_t s) {
+  const dim3 grid((unsigned)(B * ((N + 63) / 64)), (unsigned)((C + 63) / 64));
+  hipLaunchKernelGGL(k_grad_to_rows, grid, dim3(256), 0, s, src, sb, sc, sn, N, C, dx);
+  hipLaunchKernelGGL(k_unit_scale, dim3(1), dim3(64), 0, s, scale);
+  return hipGetLastError();
+}
+
 hipError_t launch_img_grad_to_levels(const float* grad_img_map, int B, int map_size, int Ct,
                                      const ListMap2D grads[LIST_N_IMG_LEVELS], hipStream_t s) {
   if (map_size > kAdjMaxMs) return hipErrorInvalidValue;

@@ -409,7 +409,10 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   if (a->B >= 0 && a->N >= 0 && (int64_t)a->B * a->N == 0) return LIST_OK;
   int rc = check_query_common(a, &L);
   if (rc != LIST_OK) return rc;
-  if (a->percep_feat) return fail(LIST_ERR_UNSUPPORTED, "backward needs the fused form (percep_feat == NULL)");
+  if (a->percep_feat && (ga->grad_img_map || ga->grad_trans_mat))
+    return fail(LIST_ERR_ARG, "with percep_feat the perceptual gradient is grad_percep_feat, not grad_img_map/grad_trans_mat");
+  if (!a->percep_feat && ga->grad_percep_feat)
+    return fail(LIST_ERR_ARG, "grad_percep_feat needs the pre-pooled form (fwd->percep_feat)");
   if (!ga->grad_sdf || !ga->packed_mlp_bwd || !a->packed_mlp || !ga->workspace)
     return fail(LIST_ERR_ARG, "grad_sdf/packed_mlp_bwd/packed_mlp/workspace is NULL");
   if (a->F != L.F) return fail(LIST_ERR_SHAPE, "F=%d but channels give %d", a->F, L.F);
@@ -543,7 +546,7 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
            "dW0 launch");
   mark(LIST_BWD_WGRAD0);
 
-  bool want_maps = ga->grad_img_map || ga->grad_trans_mat;
+  bool want_maps = ga->grad_img_map || ga->grad_trans_mat || ga->grad_percep_feat;
   for (int l = 0; l < LIST_N_VOX_LEVELS; ++l) want_maps = want_maps || ga->grad_vox[l].data;
   if (!want_maps) {
     for (int st = LIST_BWD_DGRAD0; st < LIST_N_BWD_STAGES; ++st) mark(st);
@@ -564,7 +567,7 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   ScatterParams sp;
   sp.g = make_gather(a, L, ws, 0, n_valid, crow);
   sp.g.order = order;
-  const bool pix = !a->no_sort && a->map_size * ((a->map_size + 3) / 4) <= kSortPixCells;
+  const bool pix = !a->no_sort && !a->percep_feat && a->map_size * ((a->map_size + 3) / 4) <= kSortPixCells;
   if (pix) { sp.g.order_img = (const int*)(fw + ws.order_img); sp.g.row_of = (const int*)(fw + ws.row_of); }
   sp.dx = bwp + bw.dx; sp.dx_f16 = fp16 ? 1 : 0; sp.scale = scale;
   VoxGatherBuffers vb;
@@ -572,12 +575,66 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   vb.recs = bwp + bw.vs_recs; vb.mode = ga->vox_adjoint;
   LIST_TRY(launch_scatter_vox(sp, L, *a, ga->grad_vox, vb, s), "voxel scatter launch");
   mark(LIST_BWD_VOX);
+  if (a->percep_feat) {
+    if (ga->grad_percep_feat)
+      LIST_TRY(launch_rows_to_grad(sp, L.img_off, L.img_C, a->B, (int*)(bwp + bw.vs_keys), ga->grad_percep_feat,
+                                   ga->gpf_sb, ga->gpf_sc, ga->gpf_sn, s), "grad_percep_feat launch");
+    mark(LIST_BWD_IMG); mark(LIST_BWD_TRANS);
+    return LIST_OK;
+  }
   const int nslots = a->B < kSortImages ? a->B : kSortImages;
   const int* bins_pix = pix ? (const int*)(fw + ws.bins) + (size_t)nslots * kSortCells : nullptr;
   if (pix && a->B > kSortImages) { sp.g.order_img = nullptr; sp.g.row_of = nullptr; bins_pix = nullptr; }
   LIST_TRY(launch_img_grad(sp, L, *a, bins_pix, nslots, bwp + bw.recs, ga->grad_img_map, ga->grad_trans_mat,
                            ga->stage_events, s), "image gradient launch");
 #undef LIST_TRY
+  return LIST_OK;
+}
+
+size_t list_percep_pool_bwd_workspace_bytes(int64_t n_points, int32_t img_C) {
+  if (n_points <= 0 || img_C <= 0) return 0;
+  const int64_t rows = (n_points + kGatherRows - 1) / kGatherRows * kGatherRows;
+  return align_up((size_t)rows * img_C * 4, 256) + align_up((size_t)rows * 32, 256) + 256;
+}
+
+int list_percep_pool_bwd(const ListPoolGradArgs* ga, void* stream) {
+  if (!ga || !ga->fwd) return fail(LIST_ERR_ARG, "args/fwd is NULL");
+  const ListPoolArgs* a = ga->fwd;
+  if (!a->pc || !a->trans_mat || !a->img_map || !ga->grad_out || !ga->workspace) return fail(LIST_ERR_ARG, "NULL pointer");
+  if (a->B <= 0 || a->N <= 0 || a->map_size < 2 || a->img_C <= 0 || a->img_C % 4)
+    return fail(LIST_ERR_SHAPE, "B=%d N=%d map_size=%d img_C=%d", a->B, a->N, a->map_size, a->img_C);
+  if (!dtype_ok(a->img_dtype) || (a->img_dtype == LIST_MAP_F16 && a->img_C % 8))
+    return fail(LIST_ERR_ARG, "img_dtype=%d img_C=%d", a->img_dtype, a->img_C);
+  const int64_t P = (int64_t)a->B * a->N;
+  if (P * a->img_C >= (int64_t)1 << 31) return fail(LIST_ERR_SHAPE, "B*N*img_C must stay below 2^31");
+  if (ga->workspace_bytes < list_percep_pool_bwd_workspace_bytes(P, a->img_C))
+    return fail(LIST_ERR_WORKSPACE, "workspace too small: %zu < %zu", ga->workspace_bytes,
+                list_percep_pool_bwd_workspace_bytes(P, a->img_C));
+  if (!aligned16(ga->workspace) || !aligned16(a->img_map)) return fail(LIST_ERR_SHAPE, "workspace/img_map must be 16-byte aligned");
+  const int64_t rows = (P + kGatherRows - 1) / kGatherRows * kGatherRows;
+  char* wsb = (char*)ga->workspace;
+  float* dx = (float*)wsb;
+  char* recs = wsb + align_up((size_t)rows * a->img_C * 4, 256);
+  float* scale = (float*)(recs + align_up((size_t)rows * 32, 256));
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = launch_grad_to_rows(ga->grad_out, ga->g_sb, ga->g_sc, ga->g_sn, a->B, a->N, a->img_C, dx, scale, s);
+  if (e != hipSuccess) return hip_fail(e, "grad_to_rows launch");
+  // the shared kernels take the fused call's descriptors: a point set without orders, X = the gradient rows
+  ListQueryArgs q;
+  memset(&q, 0, sizeof(q));
+  q.B = a->B; q.N = a->N; q.trans_mat = a->trans_mat; q.img_map = a->img_map; q.img_dtype = a->img_dtype;
+  q.map_size = a->map_size; q.img_C = a->img_C; q.clamp_hi = a->clamp_hi;
+  FeatLayout L;
+  memset(&L, 0, sizeof(L));
+  L.img_off = 0; L.img_C = a->img_C; L.Kp = a->img_C;
+  ScatterParams sp;
+  memset(&sp, 0, sizeof(sp));
+  sp.g.query = a->pc; sp.g.q_sb = a->p_sb; sp.g.q_sn = a->p_sn; sp.g.q_sc = a->p_sc;
+  sp.g.perm0 = 0; sp.g.perm1 = 1; sp.g.perm2 = 2; sp.g.scale = 1.f;
+  sp.g.N = a->N; sp.g.p_begin = 0; sp.g.n_valid = (int)P; sp.g.rows = (int)rows; sp.g.Kp = a->img_C;
+  sp.dx = dx; sp.dx_f16 = 0; sp.scale = scale;
+  e = launch_img_grad(sp, L, q, nullptr, 0, recs, ga->grad_img_map, ga->grad_trans_mat, nullptr, s);
+  if (e != hipSuccess) return hip_fail(e, "percep_pool_bwd launch");
   return LIST_OK;
 }
 

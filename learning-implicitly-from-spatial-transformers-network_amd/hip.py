@@ -82,7 +82,9 @@ class ListQueryGradArgs(C.Structure):
                 ("grad_img_map", C.c_void_p), ("grad_trans_mat", C.c_void_p),
                 ("grad_vox", ListVoxLevel * N_VOX_LEVELS),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-                ("stage_events", C.POINTER(C.c_void_p)), ("vox_adjoint", C.c_int32)]
+                ("stage_events", C.POINTER(C.c_void_p)), ("vox_adjoint", C.c_int32),
+                ("grad_percep_feat", C.c_void_p), ("gpf_sb", C.c_int64), ("gpf_sc", C.c_int64),
+                ("gpf_sn", C.c_int64)]
 
 
 VOX_ADJOINT = {"auto": 0, "scatter": 1, "gather": 2}
@@ -103,6 +105,12 @@ class ListPoolArgs(C.Structure):
                 ("img_map", C.c_void_p), ("img_dtype", C.c_int32), ("map_size", C.c_int32),
                 ("img_C", C.c_int32), ("clamp_hi", C.c_float),
                 ("out", C.c_void_p)]
+
+
+class ListPoolGradArgs(C.Structure):
+    _fields_ = [("fwd", C.POINTER(ListPoolArgs)), ("grad_out", C.c_void_p), ("g_sb", C.c_int64),
+                ("g_sc", C.c_int64), ("g_sn", C.c_int64), ("grad_img_map", C.c_void_p),
+                ("grad_trans_mat", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
 EXPORTS = {
@@ -132,6 +140,8 @@ EXPORTS = {
     "list_sdf_query_bwd": (C.c_int, [C.POINTER(ListQueryGradArgs), C.c_void_p]),
     "list_img_map_grad_to_levels": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(ListMap2D),
                                               C.c_void_p]),
+    "list_percep_pool_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "list_percep_pool_bwd": (C.c_int, [C.POINTER(ListPoolGradArgs), C.c_void_p]),
     "list_gemm_tn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "list_last_error": (C.c_char_p, []),
@@ -419,7 +429,9 @@ def sdf_query_backward(ctx, grad_sdf, packed_bwd, want_mlp=True, want_img=True, 
       'mlp'       : {fc_0.weight [H1,F,1], fc_0.bias, ..., fc_out.bias} (reference layouts)
       'img_map'   : gradient of the prepared perceptual map, float32 [B,ms,ms,Ct]
       'vox'       : per level float32 [B,D,H,W,C] (channels-last; .permute(0,4,1,2,3) is the NCDHW view)
-      'trans_mat' : [B,4,3]"""
+      'trans_mat' : [B,4,3]
+    For a forward with percep_feat (VoxelDecoder2.forward's own form) 'img_map'/'trans_mat' are replaced by
+      'percep_feat': [B,img_C,N], the gradient of the pre-pooled features."""
     lib = load()
     a = ctx.args
     B, N = a.B, a.N
@@ -432,6 +444,13 @@ def sdf_query_backward(ctx, grad_sdf, packed_bwd, want_mlp=True, want_img=True, 
     ga.vox_adjoint = VOX_ADJOINT[vox_adjoint]
     out = {}
     f32 = dict(dtype=torch.float32, device=dev)
+    if a.percep_feat:
+        want_trans = False
+        if want_img:
+            out["percep_feat"] = torch.empty((B, a.img_C, N), **f32)
+            ga.grad_percep_feat = out["percep_feat"].data_ptr()
+            ga.gpf_sb, ga.gpf_sc, ga.gpf_sn = out["percep_feat"].stride()
+        want_img = False
     if want_mlp:
         m = {"fc_0.weight": torch.empty((a.H1, a.F, 1), **f32), "fc_0.bias": torch.empty((a.H1,), **f32),
              "fc_1.weight": torch.empty((a.H2, a.H1, 1), **f32), "fc_1.bias": torch.empty((a.H2,), **f32),
@@ -539,6 +558,42 @@ def percep_pool(pc, trans_mat, img, clamp_hi=136.0):
     a.out = out.data_ptr()
     with torch.cuda.device(pc.device):
         _check(lib.list_percep_pool_fwd(C.byref(a), _stream()), "list_percep_pool_fwd")
+    return out
+
+
+def percep_pool_backward(pc, trans_mat, img, grad_out, want_img=True, want_trans=True, clamp_hi=136.0):
+    """Backward of percep_pool (list_percep_pool_bwd): grad_out [B,Ct,1,N] or [B,Ct,N] ->
+    {'img_map': [B,ms,ms,Ct] fp32, 'trans_mat': [B,4,3]}."""
+    lib = load()
+    _f32_cuda(pc, "pc")
+    B, N, _ = pc.shape
+    tm = _f32_cuda(trans_mat, "trans_mat").reshape(B, 4, 3).contiguous()
+    g = _f32_cuda(grad_out, "grad_out").reshape(B, img.channels, N)
+    fwd = ListPoolArgs()
+    fwd.B, fwd.N = B, N
+    fwd.pc = pc.data_ptr()
+    fwd.p_sb, fwd.p_sn, fwd.p_sc = pc.stride()
+    fwd.trans_mat = tm.data_ptr()
+    fwd.img_map, fwd.map_size, fwd.img_C = img.data.data_ptr(), img.map_size, img.channels
+    fwd.img_dtype = img.dtype
+    fwd.clamp_hi = float(clamp_hi)
+    ga = ListPoolGradArgs()
+    ga.fwd = C.pointer(fwd)
+    ga.grad_out = g.data_ptr()
+    ga.g_sb, ga.g_sc, ga.g_sn = g.stride()
+    out = {}
+    if want_img:
+        out["img_map"] = torch.empty((B, img.map_size, img.map_size, img.channels), dtype=torch.float32,
+                                     device=pc.device)
+        ga.grad_img_map = out["img_map"].data_ptr()
+    if want_trans:
+        out["trans_mat"] = torch.empty((B, 4, 3), dtype=torch.float32, device=pc.device)
+        ga.grad_trans_mat = out["trans_mat"].data_ptr()
+    nbytes = lib.list_percep_pool_bwd_workspace_bytes(B * N, img.channels)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=pc.device)
+    ga.workspace, ga.workspace_bytes = ws.data_ptr(), nbytes
+    with torch.cuda.device(pc.device):
+        _check(lib.list_percep_pool_bwd(C.byref(ga), _stream()), "list_percep_pool_bwd")
     return out
 
 

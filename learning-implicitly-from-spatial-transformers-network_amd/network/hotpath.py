@@ -1,13 +1,13 @@
 """Dispatch of the SDF query hot path (reference network/models.py:91-97) to the HIP library.
 
-Forward: always liblist_hip.so (..hip).  There is no CPU or PyTorch forward fallback: tensors that
-are not on a HIP device raise.
-Backward: the fused form (LIST.forward: perceptual pooling + decoder in one call, up to
-262 144 points per call) runs list_sdf_query_bwd -- HIP kernels for the MLP weight/data gradients, the
-voxel and perceptual-map scatters, trans_mat and the adjoint resize (`_SdfQueryHipFn`).  The two
-remaining forms (pre-pooled `percep_feat`, i.e. VoxelDecoder2.forward called on its own, and queries
-above the per-call limit) obtain gradients by re-evaluating the same mathematics with differentiable
-torch ops ON THE GPU (`_SdfQueryFn`); the forward values always come from the HIP kernels.
+Forward AND backward always run liblist_hip.so (..hip): there is no CPU or PyTorch fallback, tensors that
+are not on a HIP device raise.  Three differentiable forms, each a torch.autograd.Function over the C ABI:
+  * fused (LIST.forward, VoxelDecoder2.query): list_sdf_query_fwd / list_sdf_query_bwd -> gradients of the
+    MLP parameters, the 5 image maps (through list_img_map_grad_to_levels), the 6 voxel maps, trans_mat;
+  * pre-pooled (VoxelDecoder2.forward(p, feat, percep_feat), the reference's own call at models.py:97):
+    the same pair; the perceptual gradient comes back as d(percep_feat);
+  * PerceptualPooling.forward on its own (models.py:94): list_percep_pool_fwd / list_percep_pool_bwd.
+Queries above 262 144 points per call are cut along the point axis (one saved workspace per piece).
 Query coordinates are data in the reference's training loop (train.py:82-85) and receive no gradient.
 """
 import torch
@@ -61,99 +61,122 @@ def stencil_offsets(device, dtype=torch.float32):
                         dtype=dtype, device=device)
 
 
-def _recompute_with_torch_ops(pts, trans_mat, img_maps, vox_maps, mlp, map_size, percep=None):
-    """Differentiable re-evaluation on the device (used for gradients only)."""
-    B, N, _ = pts.shape
-    if percep is None:
-        ones = pts.new_ones(B, N, 1)
-        cam = torch.matmul(torch.cat((pts, ones), -1), trans_mat)
-        uv = (cam[..., :2] / (cam[..., 2:] + 1e-8)).clamp(0.0, 136.0)
-        half = (map_size - 1) / 2.0
-        grid2 = ((uv - half) / half).unsqueeze(1)
-        pooled = [F.grid_sample(F.interpolate(m, size=map_size, mode="bilinear", align_corners=True),
-                                grid2, align_corners=True) for m in img_maps]
-        percep = torch.cat(pooled, 1).squeeze(2)
-    grid3 = pts[:, None, None, :, :] + stencil_offsets(pts.device)[None, None, :, None, :]
-    vf = torch.cat([F.grid_sample(f, grid3, padding_mode="border", align_corners=True)
-                    for f in vox_maps], 1)
-    feats = torch.cat((vf.reshape(B, vf.shape[1] * 7, N), percep, pts.transpose(1, 2)), 1)
-    h = feats
-    for i in range(3):
-        h = F.relu(F.conv1d(h, mlp[2 * i].reshape(mlp[2 * i].shape[0], -1, 1), mlp[2 * i + 1]))
-    return F.conv1d(h, mlp[6].reshape(1, -1, 1), mlp[7]).squeeze(1)
+HIP_BACKWARD_MAX_POINTS = 262144
 
 
-class _SdfQueryFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, runner, pts_args, query, trans_mat, percep, *tensors):
-        ctx.runner, ctx.pts_args = runner, pts_args
-        ctx.has_percep = percep is not None
-        ctx.save_for_backward(query, trans_mat, percep, *tensors)
-        return runner()
-
-    @staticmethod
-    def backward(ctx, grad_out):
-        query, trans_mat, percep, *tensors = ctx.saved_tensors
-        perm, scale, map_size = ctx.pts_args
-        img_maps, vox_maps, mlp = tensors[:N_IMG], tensors[N_IMG:N_IMG + N_VOX], tensors[N_IMG + N_VOX:]
-        with torch.enable_grad():
-            leaves = [t.detach().requires_grad_(t.requires_grad) if t is not None else None
-                      for t in (trans_mat, percep, *tensors)]
-            tm, pf = leaves[0], leaves[1]
-            rest = leaves[2:]
-            pts = query.detach()[:, :, list(perm)] * scale
-            sdf = _recompute_with_torch_ops(pts, tm, rest[:N_IMG], rest[N_IMG:N_IMG + N_VOX],
-                                            rest[N_IMG + N_VOX:], map_size, pf)
-            wanted = [t for t in leaves if t is not None and t.requires_grad]
-            grads = torch.autograd.grad(sdf, wanted, grad_out, allow_unused=True) if wanted else []
-        it = iter(grads)
-        out = [next(it) if (t is not None and t.requires_grad) else None for t in leaves]
-        return (None, None, None, *out)
+def _point_chunks(B, N):
+    if B > HIP_BACKWARD_MAX_POINTS:
+        raise RuntimeError(f"batch of {B} images exceeds the {HIP_BACKWARD_MAX_POINTS}-point limit of one backward call")
+    per = max(1, HIP_BACKWARD_MAX_POINTS // B)
+    return [(n0, min(N, n0 + per)) for n0 in range(0, N, per)]
 
 
 class _SdfQueryHipFn(torch.autograd.Function):
-    """HIP forward + HIP backward.  inputs: (state, trans_mat, 5 image maps, 6 voxel maps, 8 MLP tensors)."""
+    """HIP forward + HIP backward.  inputs: (state, trans_mat | percep_feat, 5 image maps (fused form only),
+    6 voxel maps, 8 MLP tensors).  state["run"](n0, n1) evaluates the points [n0, n1) of every image and
+    returns (sdf, hip.QueryContext)."""
 
     @staticmethod
-    def forward(ctx, state, trans_mat, *tensors):
-        sdf, qctx = state["run"]()
-        ctx.state, ctx.qctx = state, qctx
-        ctx.trans_shape = trans_mat.shape
-        ctx.img_like = [t.detach() for t in tensors[:N_IMG]]      # shapes/strides of the encoder maps
-        ctx.mlp_shapes = [t.shape for t in tensors[N_IMG + N_VOX:]]
-        return sdf
+    def forward(ctx, state, lead, *tensors):
+        B, N = state["shape"]
+        ctx.state, ctx.lead_shape, ctx.n_img = state, lead.shape, state["n_img"]
+        ctx.pieces = []
+        parts = []
+        for n0, n1 in _point_chunks(B, N):
+            sdf, qctx = state["run"](n0, n1)
+            parts.append(sdf)
+            ctx.pieces.append((n0, n1, qctx))
+        ctx.img_like = [t.detach() for t in tensors[:ctx.n_img]]      # shapes/strides of the encoder maps
+        ctx.mlp_shapes = [t.shape for t in tensors[ctx.n_img + N_VOX:]]
+        return parts[0] if len(parts) == 1 else torch.cat(parts, 1)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out):
         needs = ctx.needs_input_grad
-        want_trans = bool(needs[1])
-        want_img = any(needs[2:2 + N_IMG])
-        want_vox = any(needs[2 + N_IMG:2 + N_IMG + N_VOX])
-        want_mlp = any(needs[2 + N_IMG + N_VOX:])
-        out = hip.sdf_query_backward(ctx.qctx, _f32(grad_out), ctx.state["packed_bwd"](), want_mlp=want_mlp,
-                                     want_img=want_img, want_vox=want_vox, want_trans=want_trans)
-        grads = [None, out["trans_mat"].reshape(ctx.trans_shape) if want_trans else None]
-        if want_img:
-            levels = hip.img_map_grad_to_levels(out["img_map"], ctx.img_like)
-            grads += [g if n else None for g, n in zip(levels, needs[2:2 + N_IMG])]
+        n_img, percep = ctx.n_img, ctx.state["percep"]
+        i_img, i_vox, i_mlp = 2, 2 + n_img, 2 + n_img + N_VOX
+        want_lead = bool(needs[1])                        # trans_mat (fused) or percep_feat (pre-pooled)
+        want_img = any(needs[i_img:i_vox])
+        want_vox = any(needs[i_vox:i_mlp])
+        want_mlp = any(needs[i_mlp:])
+        grad_out = _f32(grad_out)
+        total, lead_parts = None, []
+        for n0, n1, qctx in ctx.pieces:
+            out = hip.sdf_query_backward(qctx, grad_out[:, n0:n1], ctx.state["packed_bwd"](), want_mlp=want_mlp,
+                                         want_img=(want_lead if percep else want_img), want_vox=want_vox,
+                                         want_trans=(want_lead and not percep))
+            if percep and want_lead:
+                lead_parts.append(out.pop("percep_feat"))
+            if total is None:
+                total = out
+            else:                                          # further pieces of a long query: sum
+                for k, v in out.items():
+                    if k == "mlp":
+                        for kk in v:
+                            total[k][kk] += v[kk]
+                    elif k == "vox":
+                        for a, b in zip(total[k], v):
+                            a += b
+                    else:
+                        total[k] += v
+        grads = [None]
+        if percep:
+            grads.append((lead_parts[0] if len(lead_parts) == 1 else torch.cat(lead_parts, 2)).reshape(ctx.lead_shape)
+                         if want_lead else None)
         else:
-            grads += [None] * N_IMG
+            grads.append(total["trans_mat"].reshape(ctx.lead_shape) if want_lead else None)
+        if want_img and not percep:
+            levels = hip.img_map_grad_to_levels(total["img_map"], ctx.img_like)
+            grads += [g if n else None for g, n in zip(levels, needs[i_img:i_vox])]
+        else:
+            grads += [None] * n_img
         if want_vox:       # channels-last buffers seen as [B,C,D,H,W]
-            grads += [g.permute(0, 4, 1, 2, 3) if n else None
-                      for g, n in zip(out["vox"], needs[2 + N_IMG:2 + N_IMG + N_VOX])]
+            grads += [g.permute(0, 4, 1, 2, 3) if n else None for g, n in zip(total["vox"], needs[i_vox:i_mlp])]
         else:
             grads += [None] * N_VOX
         if want_mlp:
-            grads += [out["mlp"][k].reshape(shp) if n else None
-                      for k, shp, n in zip(MLP_KEYS, ctx.mlp_shapes, needs[2 + N_IMG + N_VOX:])]
+            grads += [total["mlp"][k].reshape(shp) if n else None
+                      for k, shp, n in zip(MLP_KEYS, ctx.mlp_shapes, needs[i_mlp:])]
         else:
             grads += [None] * len(MLP_KEYS)
-        ctx.qctx = None                    # releases the saved workspace (X, H1, H2)
+        ctx.pieces = None                  # releases the saved workspaces (X, H1, H2)
         return tuple(grads)
 
 
-HIP_BACKWARD_MAX_POINTS = 262144
+class _PercepPoolFn(torch.autograd.Function):
+    """PerceptualPooling.forward on its own: list_percep_pool_fwd / list_percep_pool_bwd.
+    inputs: (img (prepared), map_size, pc, trans_mat, 5 image maps)."""
+
+    @staticmethod
+    def forward(ctx, img, pc, trans_mat, *img_maps):
+        ctx.img, ctx.pc, ctx.tm = img, pc.detach(), trans_mat.detach()
+        ctx.img_like = [t.detach() for t in img_maps]
+        ctx.tm_shape = trans_mat.shape
+        return hip.percep_pool(ctx.pc, ctx.tm, img)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        needs = ctx.needs_input_grad
+        want_trans, want_img = bool(needs[2]), any(needs[3:])
+        out = hip.percep_pool_backward(ctx.pc, ctx.tm, ctx.img, _f32(grad_out).contiguous(), want_img=want_img,
+                                       want_trans=want_trans)
+        grads = [None, None, out["trans_mat"].reshape(ctx.tm_shape) if want_trans else None]
+        if want_img:
+            levels = hip.img_map_grad_to_levels(out["img_map"], ctx.img_like)
+            grads += [g if n else None for g, n in zip(levels, needs[3:])]
+        else:
+            grads += [None] * len(ctx.img_like)
+        return tuple(grads)
+
+
+def percep_pool(img_maps, pc, trans_mat, img):
+    """[B,Ct,1,N] with gradients to the image maps and trans_mat when they require them."""
+    diff = [t for t in (trans_mat, *img_maps) if t.requires_grad]
+    if torch.is_grad_enabled() and diff:
+        return _PercepPoolFn.apply(img, _f32(pc), _f32(trans_mat), *[_f32(m) for m in img_maps])
+    return hip.percep_pool(_f32(pc), _f32(trans_mat), img)
 
 
 def sdf_query(query, trans_mat, img_maps, vox_maps, mlp_params, *, perm=(2, 1, 0), scale=2.0,
@@ -185,23 +208,22 @@ def sdf_query(query, trans_mat, img_maps, vox_maps, mlp_params, *, perm=(2, 1, 0
 
     diff = [t for t in (trans_mat, percep_feat, *img_maps, *vox_maps, *mlp)
             if t is not None and t.requires_grad]
-    if torch.is_grad_enabled() and diff:
-        if percep_feat is None and query.shape[0] * query.shape[1] <= HIP_BACKWARD_MAX_POINTS \
-                and query.shape[0] * query.shape[1] > 0:
-            def run_saving():
-                return hip.sdf_query(query.detach(), trans_mat.detach(), img, vox, packed, perm=perm,
-                                     scale=scale, precision=precision, save_for_backward=True)
+    if torch.is_grad_enabled() and diff and query.shape[0] * query.shape[1] > 0:
+        q_det = query.detach()
+        tm_det = trans_mat.detach() if trans_mat is not None else None
+        pf_det = percep_feat.detach() if percep_feat is not None else None
 
-            def packed_bwd():
-                return caches.setdefault("mlpT:" + str(precision), _Cache()).get(
-                    mlp, lambda: hip.prep_mlp_weights_bwd({k: t.detach() for k, t in zip(MLP_KEYS, mlp)},
-                                                          vox.channels, img_C, precision))
-            state = {"run": run_saving, "packed_bwd": packed_bwd}
-            return _SdfQueryHipFn.apply(state, trans_mat, *img_maps, *vox_maps, *mlp)
-        if percep_feat is None:
-            tensors = (*img_maps, *vox_maps, *mlp)
-        else:   # keep the positional layout expected by backward
-            tensors = (*([vox_maps[0].new_zeros(1)] * N_IMG), *vox_maps, *mlp)
-        return _SdfQueryFn.apply(run, (tuple(perm), float(scale), map_size), query, trans_mat,
-                                 percep_feat, *tensors)
+        def run_saving(n0, n1):
+            return hip.sdf_query(q_det[:, n0:n1], tm_det, img, vox, packed, perm=perm, scale=scale,
+                                 precision=precision, save_for_backward=True,
+                                 percep_feat=pf_det[:, :, n0:n1] if pf_det is not None else None)
+
+        def packed_bwd():
+            return caches.setdefault("mlpT:" + str(precision), _Cache()).get(
+                mlp, lambda: hip.prep_mlp_weights_bwd({k: t.detach() for k, t in zip(MLP_KEYS, mlp)},
+                                                      vox.channels, img_C, precision))
+        state = {"run": run_saving, "packed_bwd": packed_bwd, "percep": percep_feat is not None,
+                 "n_img": len(img_maps), "shape": (query.shape[0], query.shape[1])}
+        lead = percep_feat if percep_feat is not None else trans_mat
+        return _SdfQueryHipFn.apply(state, lead, *img_maps, *vox_maps, *mlp)
     return run()

@@ -32,11 +32,7 @@ class PerceptualPooling(nn.Module):
 
     def forward(self, img_featuremaps, pc, trans_mat):
         hotpath.require_hip(pc, "PerceptualPooling.forward(pc)")
-        if torch.is_grad_enabled() and (trans_mat.requires_grad or any(m.requires_grad for m in img_featuremaps)):
-            raise RuntimeError("PerceptualPooling.forward is forward-only on the HIP path; call it under "
-                               "torch.no_grad(), or use LIST.forward / VoxelDecoder2.query, whose fused "
-                               "autograd function provides gradients")
-        return hip.percep_pool(pc.float(), trans_mat.float(), self.prepared(img_featuremaps))
+        return hotpath.percep_pool(list(img_featuremaps), pc, trans_mat, self.prepared(img_featuremaps))
 
     def __repr__(self):
         return f"{self.__class__.__name__} (Map pc to {self.map_size} x {self.map_size} plane)"
