@@ -264,6 +264,11 @@ typedef struct ListQueryGradArgs {
                                       /*   the level fits the sort's bins.  Same values up to summation order */
   float* grad_percep_feat;            /* only with fwd->percep_feat (VoxelDecoder2.forward's own form): the    */
   int64_t gpf_sb, gpf_sc, gpf_sn;     /*   gradient of the pre-pooled features, [B,img_C,N] with these strides */
+  void* aux_streams[2];               /* optional: two more hipStream_t of the same device.  The backward is a   */
+                                      /*   DAG, not a chain: dW0 (MFMA-bound), the atomic-rate-bound scatters,   */
+                                      /*   the LDS-window scatters and the gathers need different units, so they */
+                                      /*   are forked onto these streams (event fork/join around them: the call  */
+                                      /*   is still ordered on `stream` as a whole).  NULL: everything in order. */
 } ListQueryGradArgs;
 
 enum ListBwdStage {
@@ -273,8 +278,8 @@ enum ListBwdStage {
   LIST_BWD_DGRAD2 = 3,    /* k_gemm_nt: dH2 (masked) */
   LIST_BWD_WGRAD1 = 4,
   LIST_BWD_DGRAD1 = 5,
-  LIST_BWD_WGRAD0 = 6,    /* k_gemm_tn: dW0 [512 x 3648], the large one */
-  LIST_BWD_DGRAD0 = 7,    /* k_gemm_nt: dX [P x 3648] */
+  LIST_BWD_DGRAD0 = 6,    /* k_gemm_nt: dX [P x 3648] */
+  LIST_BWD_WGRAD0 = 7,    /* k_gemm_tn: dW0 [512 x 3648], the large one (enqueue time only when forked) */
   LIST_BWD_VOX = 8,       /* scatter-add into the voxel levels */
   LIST_BWD_IMG = 9,       /* gradient of the prepared perceptual map */
   LIST_BWD_TRANS = 10,    /* gradient of trans_mat */

@@ -57,13 +57,21 @@ __device__ __forceinline__ void scatter_direct(const ScatterParams& sp, const Li
   }
 }
 
+// Persistent grid (kDirectGrid workgroups walk the 64-row blocks): the kernel runs at the memory side's
+// atomic rate whatever its occupancy, so it keeps to two workgroups per CU and leaves the wave slots to the
+// kernels that run beside it on the other streams (ListQueryGradArgs.aux_streams).
+constexpr int kDirectGrid = 512;
+
 template <int C, int DXH>
-__global__ __launch_bounds__(256) void k_scatter_vox(ScatterParams sp, ListVoxLevel gv, int col_off) {
+__global__ __launch_bounds__(256) void k_scatter_vox(ScatterParams sp, ListVoxLevel gv, int col_off, int nblocks) {
   __shared__ Pt pts[kScatterRows];
-  const int blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
-  if (threadIdx.x < kScatterRows) pts[threadIdx.x] = load_point(sp.g, blk * kScatterRows + threadIdx.x);
-  __syncthreads();
-  scatter_direct<C, DXH>(sp, gv, col_off, pts, 0, kScatterRows, (int64_t)blk * kScatterRows, sp.scale[1]);
+  const float inv_s = sp.scale[1];
+  for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    __syncthreads();
+    if (threadIdx.x < kScatterRows) pts[threadIdx.x] = load_point(sp.g, blk * kScatterRows + threadIdx.x);
+    __syncthreads();
+    scatter_direct<C, DXH>(sp, gv, col_off, pts, 0, kScatterRows, (int64_t)blk * kScatterRows, inv_s);
+  }
 }
 
 // Coarse levels (stencil shorter than a voxel: 16^3 and 8^3, 58 % of all tap contributions): a run of
@@ -431,17 +439,18 @@ static hipError_t gather_level(const ScatterParams& sp, const ListVoxLevel& gv, 
 // scalar (C == 1) levels: one lane per (point, stencil point)
 template <int DXH>
 __global__ __launch_bounds__(256) void k_scatter_vox1(ScatterParams sp, ListVoxLevel gv, int col_off) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  const int row = t >> 3, j = t & 7;
-  if (row >= sp.g.n_valid || j >= LIST_N_STENCIL) return;
-  const Pt p = load_point(sp.g, row);
-  float x, y, z;
-  stencil_rt(p, j, x, y, z);
-  const Taps tp = make_taps(x, y, z, 1, gv.D, gv.H, gv.W);
-  const float gval = dx_at<DXH>(sp.dx, (int64_t)row * sp.g.Kp + col_off + j) * sp.scale[1];
-  float* base = (float*)gv.data + (int64_t)p.b * gv.image_stride;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < sp.g.n_valid * 8; t += gridDim.x * 256) {
+    const int row = t >> 3, j = t & 7;
+    if (j >= LIST_N_STENCIL) continue;
+    const Pt p = load_point(sp.g, row);
+    float x, y, z;
+    stencil_rt(p, j, x, y, z);
+    const Taps tp = make_taps(x, y, z, 1, gv.D, gv.H, gv.W);
+    const float gval = dx_at<DXH>(sp.dx, (int64_t)row * sp.g.Kp + col_off + j) * sp.scale[1];
+    float* base = (float*)gv.data + (int64_t)p.b * gv.image_stride;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) atomicAdd(base + tp.o[k], tp.w[k] * gval);
+    for (int k = 0; k < 8; ++k) atomicAdd(base + tp.o[k], tp.w[k] * gval);
+  }
 }
 
 template <int C>
@@ -462,14 +471,16 @@ static hipError_t scatter_level(const ScatterParams& sp, const ListVoxLevel& gv,
       return hipGetLastError();
     }
   }
-  if (sp.dx_f16) hipLaunchKernelGGL((k_scatter_vox<C, 1>), grid, dim3(256), 0, s, sp, gv, col_off);
-  else hipLaunchKernelGGL((k_scatter_vox<C, 0>), grid, dim3(256), 0, s, sp, gv, col_off);
+  const int nblocks = sp.g.rows / kScatterRows;
+  const dim3 pgrid((unsigned)(nblocks < kDirectGrid ? nblocks : kDirectGrid));
+  if (sp.dx_f16) hipLaunchKernelGGL((k_scatter_vox<C, 1>), pgrid, dim3(256), 0, s, sp, gv, col_off, nblocks);
+  else hipLaunchKernelGGL((k_scatter_vox<C, 0>), pgrid, dim3(256), 0, s, sp, gv, col_off, nblocks);
   return hipGetLastError();
 }
 
 hipError_t launch_scatter_vox(const ScatterParams& sp, const FeatLayout& L, const ListQueryArgs& a,
                               const ListVoxLevel grad_vox[LIST_N_VOX_LEVELS], const VoxGatherBuffers& vb,
-                              hipStream_t s) {
+                              const ScatterStreams& st) {
   (void)a;
   const int B = (int)((sp.g.p_begin + sp.g.n_valid + sp.g.N - 1) / sp.g.N);
   for (int l = 0; l < LIST_N_VOX_LEVELS; ++l) {
@@ -485,19 +496,21 @@ hipError_t launch_scatter_vox(const ScatterParams& sp, const FeatLayout& L, cons
     if (vb.bins && dense && n_vox <= kVoxGatherMaxBins && (gv.C == 16 || gv.C == 32 || gv.C == 64 ||
                                                                            gv.C == 128 || gv.C == 256)) {
       switch (gv.C) {
-        case 16: e = gather_level<16>(sp, gv, L.vox_off[l], B, vb, s); break;
-        case 32: e = gather_level<32>(sp, gv, L.vox_off[l], B, vb, s); break;
-        case 64: e = gather_level<64>(sp, gv, L.vox_off[l], B, vb, s); break;
-        case 128: e = gather_level<128>(sp, gv, L.vox_off[l], B, vb, s); break;
-        default: e = gather_level<256>(sp, gv, L.vox_off[l], B, vb, s); break;
+        case 16: e = gather_level<16>(sp, gv, L.vox_off[l], B, vb, st.gather); break;
+        case 32: e = gather_level<32>(sp, gv, L.vox_off[l], B, vb, st.gather); break;
+        case 64: e = gather_level<64>(sp, gv, L.vox_off[l], B, vb, st.gather); break;
+        case 128: e = gather_level<128>(sp, gv, L.vox_off[l], B, vb, st.gather); break;
+        default: e = gather_level<256>(sp, gv, L.vox_off[l], B, vb, st.gather); break;
       }
       if (e != hipSuccess) return e;
       continue;
     }
+    hipStream_t s = (window_level && vb.mode != 2) ? st.window : st.direct;
     e = hipMemsetAsync((void*)gv.data, 0, (size_t)B * gv.image_stride * sizeof(float), s);
     if (e != hipSuccess) return e;
     if (gv.C == 1) {
-      const dim3 grid((unsigned)((sp.g.n_valid * 8 + 255) / 256));
+      const int nb1 = (sp.g.n_valid * 8 + 255) / 256;
+      const dim3 grid((unsigned)(nb1 < 4 * kDirectGrid ? nb1 : 4 * kDirectGrid));
       if (sp.dx_f16) hipLaunchKernelGGL(k_scatter_vox1<1>, grid, dim3(256), 0, s, sp, gv, L.vox_off[l]);
       else hipLaunchKernelGGL(k_scatter_vox1<0>, grid, dim3(256), 0, s, sp, gv, L.vox_off[l]);
       e = hipGetLastError();

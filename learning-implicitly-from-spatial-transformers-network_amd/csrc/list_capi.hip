@@ -492,8 +492,22 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   mark(LIST_BWD_HEAD);
 
   // one layer of the chain: weight gradient (TN), bias gradient, then the masked data gradient (NT)
+  // optional fork/join onto the caller's auxiliary streams (see ListQueryGradArgs.aux_streams)
+  hipStream_t s_direct = s, s_window = s;
+  const bool forked = ga->aux_streams[0] && ga->aux_streams[1];
+  if (forked) { s_direct = (hipStream_t)ga->aux_streams[0]; s_window = (hipStream_t)ga->aux_streams[1]; }
+  auto hand_over = [&](hipStream_t from, hipStream_t to) -> hipError_t {      // `to` continues after `from`'s work so far
+    if (from == to) return hipSuccess;
+    hipEvent_t ev;
+    hipError_t err = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (err != hipSuccess) return err;
+    err = hipEventRecord(ev, from);
+    if (err == hipSuccess) err = hipStreamWaitEvent(to, ev, 0);
+    (void)hipEventDestroy(ev);                    // released once the wait has been satisfied
+    return err;
+  };
   auto wgrad = [&](size_t dz_hi, size_t dz_lo, int M, const char* act_hi, const char* act_lo, int N, int ldb,
-                   const FeatLayout* layout, float* out, int ldo) -> hipError_t {
+                   const FeatLayout* layout, float* out, int ldo, hipStream_t s) -> hipError_t {
     if (!out) return hipSuccess;
     GemmTnParams tp;
     memset(&tp, 0, sizeof(tp));
@@ -523,7 +537,7 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
 
   // fc_2
   LIST_TRY(wgrad(bw.dz3_hi, bw.dz3_lo, a->H3, fw + ws.h2_hi, fw + ws.h2_lo, a->H2, a->H2, nullptr, ga->mlp.w2,
-                 a->H2), "dW2 launch");
+                 a->H2, s), "dW2 launch");
   mark(LIST_BWD_WGRAD2);
   LIST_TRY(dgrad(bw.dz3_hi, bw.dz3_lo, a->H3, wt + pb.w2t_hi, wt + pb.w2t_lo, a->H2, fw + ws.h2_hi, bw.dz2_hi,
                  bw.dz2_lo), "dH2 launch");
@@ -533,7 +547,7 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
     LIST_TRY(launch_colsum(plane(bw.dz2_hi), lo ? plane(bw.dz2_lo) : nullptr, crow, n_valid, a->H2, fmt, nullptr,
                            nullptr, scale, 1, colsum, ga->mlp.b1, s), "d fc_1.bias launch");
   LIST_TRY(wgrad(bw.dz2_hi, bw.dz2_lo, a->H2, fw + ws.h1_hi, fw + ws.h1_lo, a->H1, a->H1, nullptr, ga->mlp.w1,
-                 a->H1), "dW1 launch");
+                 a->H1, s), "dW1 launch");
   mark(LIST_BWD_WGRAD1);
   LIST_TRY(dgrad(bw.dz2_hi, bw.dz2_lo, a->H2, wt + pb.w1t_hi, wt + pb.w1t_lo, a->H1, fw + ws.h1_hi, bw.dz1_hi,
                  bw.dz1_lo), "dH1 launch");
@@ -542,13 +556,11 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   if (ga->mlp.b0)
     LIST_TRY(launch_colsum(plane(bw.dz1_hi), lo ? plane(bw.dz1_lo) : nullptr, crow, n_valid, a->H1, fmt, nullptr,
                            nullptr, scale, 1, colsum, ga->mlp.b0, s), "d fc_0.bias launch");
-  LIST_TRY(wgrad(bw.dz1_hi, bw.dz1_lo, a->H1, fw + ws.x_hi, fw + ws.x_lo, L.Kp, L.Kp, &L, ga->mlp.w0, L.F),
-           "dW0 launch");
-  mark(LIST_BWD_WGRAD0);
-
   bool want_maps = ga->grad_img_map || ga->grad_trans_mat || ga->grad_percep_feat;
   for (int l = 0; l < LIST_N_VOX_LEVELS; ++l) want_maps = want_maps || ga->grad_vox[l].data;
   if (!want_maps) {
+    LIST_TRY(wgrad(bw.dz1_hi, bw.dz1_lo, a->H1, fw + ws.x_hi, fw + ws.x_lo, L.Kp, L.Kp, &L, ga->mlp.w0, L.F, s),
+             "dW0 launch");
     for (int st = LIST_BWD_DGRAD0; st < LIST_N_BWD_STAGES; ++st) mark(st);
     return LIST_OK;
   }
@@ -573,13 +585,24 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   VoxGatherBuffers vb;
   vb.keys = (int*)(bwp + bw.vs_keys); vb.bins = (int*)(bwp + bw.vs_bins); vb.sums = (int*)(bwp + bw.vs_sums);
   vb.recs = bwp + bw.vs_recs; vb.mode = ga->vox_adjoint;
-  LIST_TRY(launch_scatter_vox(sp, L, *a, ga->grad_vox, vb, s), "voxel scatter launch");
+  // dX is ready on `s`.  From here the work is a DAG of stages bound by different units: dW0 (MFMA; needs only
+  // dZ1 and X) and the LDS-window levels on one stream, the atomic-rate-bound levels on another, the gathers
+  // (voxel-side gather, perceptual map, trans_mat) on `s`.  Without auxiliary streams: the same order, in line.
+  LIST_TRY(hand_over(s, s_direct), "stream fork");
+  LIST_TRY(hand_over(s, s_window), "stream fork");
+  LIST_TRY(wgrad(bw.dz1_hi, bw.dz1_lo, a->H1, fw + ws.x_hi, fw + ws.x_lo, L.Kp, L.Kp, &L, ga->mlp.w0, L.F, s_window),
+           "dW0 launch");
+  mark(LIST_BWD_WGRAD0);
+  const ScatterStreams sst = {s, s_direct, s_window};
+  LIST_TRY(launch_scatter_vox(sp, L, *a, ga->grad_vox, vb, sst), "voxel scatter launch");
   mark(LIST_BWD_VOX);
   if (a->percep_feat) {
     if (ga->grad_percep_feat)
       LIST_TRY(launch_rows_to_grad(sp, L.img_off, L.img_C, a->B, (int*)(bwp + bw.vs_keys), ga->grad_percep_feat,
                                    ga->gpf_sb, ga->gpf_sc, ga->gpf_sn, s), "grad_percep_feat launch");
     mark(LIST_BWD_IMG); mark(LIST_BWD_TRANS);
+    LIST_TRY(hand_over(s_direct, s), "stream join");
+    LIST_TRY(hand_over(s_window, s), "stream join");
     return LIST_OK;
   }
   const int nslots = a->B < kSortImages ? a->B : kSortImages;
@@ -587,6 +610,8 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   if (pix && a->B > kSortImages) { sp.g.order_img = nullptr; sp.g.row_of = nullptr; bins_pix = nullptr; }
   LIST_TRY(launch_img_grad(sp, L, *a, bins_pix, nslots, bwp + bw.recs, ga->grad_img_map, ga->grad_trans_mat,
                            ga->stage_events, s), "image gradient launch");
+  LIST_TRY(hand_over(s_direct, s), "stream join");
+  LIST_TRY(hand_over(s_window, s), "stream join");
 #undef LIST_TRY
   return LIST_OK;
 }

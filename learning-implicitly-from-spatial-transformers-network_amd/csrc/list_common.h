@@ -368,9 +368,11 @@ struct ScatterParams {
 constexpr int64_t kVoxGatherMaxBins = 4194304;      // cells (B * D * H * W) a level may have
 constexpr double kVoxGatherMinDensity = LIST_VOX_GATHER_MIN_DENSITY;   // samples per cell
 struct VoxGatherBuffers { int* keys; int* bins; int* sums; void* recs; int mode; };   // mode: ListQueryGradArgs.vox_adjoint
+// the three adjoint forms may run on different streams (gather / direct atomics / LDS windows)
+struct ScatterStreams { hipStream_t gather, direct, window; };
 hipError_t launch_scatter_vox(const ScatterParams& sp, const FeatLayout& L, const ListQueryArgs& a,
                               const ListVoxLevel grad_vox[LIST_N_VOX_LEVELS], const VoxGatherBuffers& vb,
-                              hipStream_t s);
+                              const ScatterStreams& st);
 hipError_t launch_img_grad(const ScatterParams& sp, const FeatLayout& L, const ListQueryArgs& a,
                            const int* bins_pix, int nslots, void* recs, float* grad_img_map,
                            float* grad_trans_mat, void* const* stage_events, hipStream_t s);

@@ -84,12 +84,12 @@ class ListQueryGradArgs(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("stage_events", C.POINTER(C.c_void_p)), ("vox_adjoint", C.c_int32),
                 ("grad_percep_feat", C.c_void_p), ("gpf_sb", C.c_int64), ("gpf_sc", C.c_int64),
-                ("gpf_sn", C.c_int64)]
+                ("gpf_sn", C.c_int64), ("aux_streams", C.c_void_p * 2)]
 
 
 VOX_ADJOINT = {"auto": 0, "scatter": 1, "gather": 2}
 N_BWD_STAGES = 11
-BWD_STAGE_NAMES = ("head", "wgrad_fc2", "dgrad_fc2", "wgrad_fc1", "dgrad_fc1", "wgrad_fc0", "dgrad_fc0",
+BWD_STAGE_NAMES = ("head", "wgrad_fc2", "dgrad_fc2", "wgrad_fc1", "dgrad_fc1", "dgrad_fc0", "wgrad_fc0",
                    "scatter_vox", "img_map_grad", "trans_mat_grad")
 
 N_STAGES = 12
@@ -423,8 +423,21 @@ def sdf_query(query, trans_mat, img, vox, packed, perm=(2, 1, 0), scale=2.0, pre
     return sdf
 
 
+_aux_streams = {}
+
+
+def _aux(device):
+    """Two side streams per (device, thread) for the forked stages of list_sdf_query_bwd."""
+    key = (device.index, threading.get_ident())
+    st = _aux_streams.get(key)
+    if st is None:
+        st = (torch.cuda.Stream(device), torch.cuda.Stream(device))
+        _aux_streams[key] = st
+    return st
+
+
 def sdf_query_backward(ctx, grad_sdf, packed_bwd, want_mlp=True, want_img=True, want_vox=True,
-                       want_trans=True, stage_events=None, vox_adjoint="auto"):
+                       want_trans=True, stage_events=None, vox_adjoint="auto", overlap=True):
     """Backward of sdf_query (list_sdf_query_bwd).  Returns a dict:
       'mlp'       : {fc_0.weight [H1,F,1], fc_0.bias, ..., fc_out.bias} (reference layouts)
       'img_map'   : gradient of the prepared perceptual map, float32 [B,ms,ms,Ct]
@@ -482,6 +495,9 @@ def sdf_query_backward(ctx, grad_sdf, packed_bwd, want_mlp=True, want_img=True, 
     ga.workspace, ga.workspace_bytes = ws.data_ptr(), nbytes
     if stage_events is not None:
         ga.stage_events = C.cast(stage_events, C.POINTER(C.c_void_p))
+    if overlap:        # dW0 | atomic scatters | window scatters | gathers run side by side (joined before return)
+        a0, a1 = _aux(dev)
+        ga.aux_streams[0], ga.aux_streams[1] = a0.cuda_stream, a1.cuda_stream
     with torch.cuda.device(dev):
         _check(lib.list_sdf_query_bwd(C.byref(ga), _stream()), "list_sdf_query_bwd")
     return out
