@@ -3,14 +3,14 @@
 //   * gradient of the prepared 137^2 perceptual map   (adjoint of F.grid_sample 2-D, modules.py:46-52)
 //   * gradient of trans_mat                           (through modules.py:37-45: matmul, divide, clamp)
 //   * gradients of the five encoder maps              (adjoint of F.interpolate, modules.py:26-35)
-// HBM / atomic-rate bound (global float atomics run at ~1.3 TB/s chip-wide on MI355X), so the design
-// goal is FEWER atomics, shaped as 256-B runs along the channel axis:
-//   * coarse voxel levels: the rows are in Morton order, so the 64 points of a workgroup touch a small
-//     box of voxels; their 64 x 7 x 8 tap contributions are first summed in an LDS window (ds_add_f32)
-//     and the window is flushed once (10-60x fewer global atomics); fine levels whose box does not fit
-//     go straight to global atomics, lanes over channels;
-//   * perceptual map: no atomics at all -- the points are already in pixel order (forward's second sort),
-//     so every map pixel GATHERS the contributions of the <= 4 pixel cells around it and is written once.
+// HBM / atomic-rate bound: global float atomics run at ~1.3 TB/s chip-wide on MI355X whatever the kernel does,
+// so the design goal is FEWER atomic bytes, shaped as runs along the channel axis.  Per voxel level one of
+//   * global atomics, lanes over channels            (fine levels: 56 distinct taps per point, nothing to merge)
+//   * voxel-side gather over cell-sorted samples      (dense middle level: written once, no atomics)
+//   * LDS windows over runs of Morton-ordered points  (coarse levels: summed on chip without atomics -- every
+//                                                     thread owns one channel column --, flushed once)
+// and for the perceptual map no atomics at all: the points are already in pixel order (forward's second
+// sort), so every map pixel GATHERS the contributions of the <= 4 pixel cells around it and is written once.
 #include <limits.h>
 
 #include "list_common.h"
