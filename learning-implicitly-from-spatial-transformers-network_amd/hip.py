@@ -335,6 +335,7 @@ def _workspace(device, nbytes):
 
 def release_workspaces():
     _workspaces.clear()
+    _aux_streams.clear()
 
 
 def _fill_query_args(query, perm, scale, vox, packed, precision, trans_mat=None, img=None,
