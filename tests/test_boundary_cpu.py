@@ -63,6 +63,25 @@ def test_hot_path_has_no_cpu_fallback(cfg):
     with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
         M.PerceptualPooling()([torch.rand(1, 4, 8, 8)] * 5, torch.rand(1, 3, 3), torch.rand(1, 4, 3))
     assert "oracle" not in open(M.__file__).read()
+    # gradients do not change that: every differentiable form goes through the C ABI (no torch-op re-evaluation)
+    from list_amd.network import hotpath
+    src = open(hotpath.__file__).read()
+    assert "grid_sample" not in src and "conv1d" not in src and "oracle" not in src
+    with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
+        M.PerceptualPooling()([torch.rand(1, 4, 8, 8, requires_grad=True)] * 5, torch.rand(1, 3, 3),
+                              torch.rand(1, 4, 3, requires_grad=True))
+
+
+def test_long_queries_are_cut_at_the_backward_limit():
+    from list_amd.network import hotpath
+    assert hotpath._point_chunks(8, 20000) == [(0, 20000)]
+    pieces = hotpath._point_chunks(1, 16777216)                   # a 256^3 grid of one image
+    assert pieces[0] == (0, 262144) and pieces[-1][1] == 16777216 and len(pieces) == 64
+    assert all(b - a <= 262144 for a, b in pieces) and all(p[1] == q[0] for p, q in zip(pieces, pieces[1:]))
+    pieces = hotpath._point_chunks(3, 100000)                     # per-image share of the limit
+    assert all(3 * (b - a) <= 262144 for a, b in pieces) and pieces[-1][1] == 100000
+    with pytest.raises(RuntimeError):
+        hotpath._point_chunks(300000, 1)
 
 
 def test_sdf_loss_and_grid_match_reference(golden_dir):
