@@ -5,9 +5,9 @@
 
 Correction (MI355X_MICROARCH.md, HBM section): on gfx950 FETCH_SIZE reports exactly half of the bytes
 of a wide (16 B/lane) coalesced read -> doubled; WRITE_SIZE is exact for 16 B/lane streaming stores.
-Both counters are in KB.  Kernels whose accesses are narrower (the 2-B epilogue stores of k_gemm_nt,
-the 8-B feature stores of the gathers) are outside the calibrated range: their numbers are kept but
-flagged "uncalibrated_writes".
+Both counters are in KB.  Kernels whose accesses are narrower (the 8-B feature stores of the gathers, the
+4-B sdf stores of the fused last layer) are outside the calibrated range: their numbers are kept but
+flagged "uncalibrated_writes".  (fc_0 / fc_1 store 16 B per lane since the LDS-staged epilogue.)
 """
 import csv
 import glob
@@ -60,7 +60,7 @@ def main():
     fetch_dir, write_dir, precision = sys.argv[1:4]
     out = sys.argv[4] if len(sys.argv) > 4 else "profiles/pmc_traffic.json"
     fetch, write = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
-    groups = {"prep_vox_ndhwc": 5, "prep_img_resize_nhwc": 5, "sort_points": 6}   # launches per step
+    groups = {"prep_vox_ndhwc": 5, "prep_img_resize_nhwc": 5, "sort_points": 3}   # launches per step
     res = {}
     for k in sorted(set(fetch) | set(write)):
         n = groups.get(k, 1)
@@ -68,7 +68,7 @@ def main():
         w_kb = sum(write.get(k, [])) / max(len(write.get(k, [])), 1) * n
         res[k] = {"hbm_bytes": 2 * f_kb * 1024 + w_kb * 1024, "fetch_size_kb_raw": f_kb,
                   "write_size_kb_raw": w_kb, "fetch_correction": 2.0,
-                  "uncalibrated_writes": k.startswith("fc_") or k.startswith("gather")}
+                  "uncalibrated_writes": k == "fc_2_out" or k.startswith("gather")}
     data = json.load(open(out)) if os.path.exists(out) else {}
     data[precision] = res
     json.dump(data, open(out, "w"), indent=1, sort_keys=True)
