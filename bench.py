@@ -241,6 +241,40 @@ def run_train_step(precision, steps, warmup, inp, hip, ev):
             "outputs": "d fc_0..fc_out (reference layout), d 5 image maps, d 6 voxel maps, d trans_mat"}, grads
 
 
+def run_whole_model(workload, precision, device, steps=5, warmup=2):
+    """the whole LIST.forward (ResNet encoders, coarse point decoder, on-device create_occ, 3-D
+    encoder, spatial transformer AND the HIP query path) on the same B x N, so the weight of the path
+    inside the model is visible.  Random-init weights (seed 333), images U[0,1)."""
+    from list_amd import arguments, utils
+    B, N, img_res, vox_res, _, _ = WORKLOADS[workload]
+    torch.manual_seed(333)
+    cfg = arguments.default_config(vox_res=vox_res, train_batch_size=B, precision=precision, img_res=img_res)
+    net = utils.get_class("network.models.LIST")(cfg).to(device).eval()
+    g = torch.Generator(device=device)
+    g.manual_seed(333)
+    img = torch.rand((B, 3, img_res, img_res), generator=g, device=device)
+    query = torch.rand((B, N, 3), generator=g, device=device) - 0.5
+    times = {"encode": 0.0, "query": 0.0}
+    with torch.no_grad():
+        for it in range(warmup + steps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            feat_l2, vox_feat, tm, _, _ = net.encode(img)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            sdf = net.query_sdf(query, feat_l2, vox_feat, tm)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            if it >= warmup:
+                times["encode"] += t1 - t0
+                times["query"] += t2 - t1
+    total = (times["encode"] + times["query"]) / steps
+    return {"model": "network.models.LIST (random init, eval)", "precision": precision,
+            "ms_per_forward": total * 1e3, "value": B * N / total, "unit": "query-points/s (whole LIST.forward)",
+            "encode_ms": times["encode"] / steps * 1e3, "query_sdf_ms": times["query"] / steps * 1e3,
+            "channels_last_encoders": bool(net.channels_last), "finite": bool(torch.isfinite(sdf).all())}
+
+
 def roofline_of(kernel_ms, table, precision):
     """Roofline entry of the longest single kernel launch."""
     # candidates are single kernel launches; the two prep entries are groups of up to five launches
@@ -277,6 +311,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-channels-last-alt", action="store_true")
     ap.add_argument("--no-train-step", action="store_true")
+    ap.add_argument("--whole-model", action="store_true",
+                    help="also time the whole LIST.forward (encoders included) on the same B x N")
     ap.add_argument("--cpu-sample-images", type=int, default=2)
     args = ap.parse_args()
 
@@ -346,6 +382,10 @@ def main():
     train_grads = None
     if args.precision is None and not args.no_train_step and B * N <= 262144:
         train, train_grads = run_train_step(headline, max(2, args.steps // 2), min(args.warmup, 2), inp, hip, ev)
+
+    whole = None
+    if args.whole_model and rank == 0:
+        whole = run_whole_model(args.workload, headline, device)
 
     if rank != 0:
         if world > 1:
@@ -448,6 +488,7 @@ def main():
         "alt": alt,
         "alt_channels_last_inputs": alt_cl,
         "train_step": train,
+        "whole_model": whole,
     }
     print(json.dumps(out))
     if world > 1:
