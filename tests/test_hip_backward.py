@@ -261,6 +261,17 @@ def test_backward_with_more_images_than_sort_slots(hip):
     compare_with_oracle(hip, margin_case(make, range(3200, 3260)))
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16"])
+def test_zero_upstream_gradient_gives_exact_zeros(hip, precision):
+    """d(loss)/d(sdf) = 0 (e.g. a masked batch): every output is written, finite and exactly zero (the fp16
+    gradient scale falls back to 1)."""
+    c = cases.build_case("gtiny")
+    _, got = hip_gradients(hip, c, np.zeros(c["query"].shape[:2], np.float32), precision)
+    assert len(got) == 21
+    for k, v in got.items():
+        assert np.isfinite(v).all() and not v.any(), k
+
+
 # ------------------------------------------------------------------------------------------ errors
 def test_backward_rejects_unsupported_calls(hip):
     c = cases.build_case("gtiny")
