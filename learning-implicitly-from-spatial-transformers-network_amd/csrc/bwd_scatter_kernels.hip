@@ -57,10 +57,12 @@ __device__ __forceinline__ void scatter_direct(const ScatterParams& sp, const Li
   }
 }
 
-// Persistent grid (kDirectGrid workgroups walk the 64-row blocks): the kernel runs at the memory side's
-// atomic rate whatever its occupancy, so it keeps to two workgroups per CU and leaves the wave slots to the
-// kernels that run beside it on the other streams (ListQueryGradArgs.aux_streams).
-constexpr int kDirectGrid = 512;
+// Persistent grid (workgroups walk the 64-row blocks).  Alone, two workgroups per CU reach the atomic rate
+// (512: 1.73 ms for the three fine levels; 128: +28 %, 64: 2.1x -- the rate is partly a per-CU issue
+// limit).  Beside other kernels (ListQueryGradArgs.aux_streams) a small grid is better for the whole: the
+// atomics of a CU fill its vector-memory queue, and every load of a neighbouring gather kernel waits behind
+// them (backward 5.92 ms with 512 workgroups, 5.57 ms with 128).
+constexpr int kDirectGrid = 512, kDirectGridForked = 128;
 
 template <int C, int DXH>
 __global__ __launch_bounds__(256) void k_scatter_vox(ScatterParams sp, ListVoxLevel gv, int col_off, int nblocks) {
@@ -472,7 +474,8 @@ static hipError_t scatter_level(const ScatterParams& sp, const ListVoxLevel& gv,
     }
   }
   const int nblocks = sp.g.rows / kScatterRows;
-  const dim3 pgrid((unsigned)(nblocks < kDirectGrid ? nblocks : kDirectGrid));
+  const int cap = sp.forked ? kDirectGridForked : kDirectGrid;
+  const dim3 pgrid((unsigned)(nblocks < cap ? nblocks : cap));
   if (sp.dx_f16) hipLaunchKernelGGL((k_scatter_vox<C, 1>), pgrid, dim3(256), 0, s, sp, gv, col_off, nblocks);
   else hipLaunchKernelGGL((k_scatter_vox<C, 0>), pgrid, dim3(256), 0, s, sp, gv, col_off, nblocks);
   return hipGetLastError();
@@ -510,7 +513,8 @@ hipError_t launch_scatter_vox(const ScatterParams& sp, const FeatLayout& L, cons
     if (e != hipSuccess) return e;
     if (gv.C == 1) {
       const int nb1 = (sp.g.n_valid * 8 + 255) / 256;
-      const dim3 grid((unsigned)(nb1 < 4 * kDirectGrid ? nb1 : 4 * kDirectGrid));
+      const int cap1 = 4 * (sp.forked ? kDirectGridForked : kDirectGrid);
+      const dim3 grid((unsigned)(nb1 < cap1 ? nb1 : cap1));
       if (sp.dx_f16) hipLaunchKernelGGL(k_scatter_vox1<1>, grid, dim3(256), 0, s, sp, gv, L.vox_off[l]);
       else hipLaunchKernelGGL(k_scatter_vox1<0>, grid, dim3(256), 0, s, sp, gv, L.vox_off[l]);
       e = hipGetLastError();

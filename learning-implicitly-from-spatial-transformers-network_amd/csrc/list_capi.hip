@@ -581,7 +581,7 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   sp.g.order = order;
   const bool pix = !a->no_sort && !a->percep_feat && a->map_size * ((a->map_size + 3) / 4) <= kSortPixCells;
   if (pix) { sp.g.order_img = (const int*)(fw + ws.order_img); sp.g.row_of = (const int*)(fw + ws.row_of); }
-  sp.dx = bwp + bw.dx; sp.dx_f16 = fp16 ? 1 : 0; sp.scale = scale;
+  sp.dx = bwp + bw.dx; sp.dx_f16 = fp16 ? 1 : 0; sp.scale = scale; sp.forked = forked ? 1 : 0;
   VoxGatherBuffers vb;
   vb.keys = (int*)(bwp + bw.vs_keys); vb.bins = (int*)(bwp + bw.vs_bins); vb.sums = (int*)(bwp + bw.vs_sums);
   vb.recs = bwp + bw.vs_recs; vb.mode = ga->vox_adjoint;

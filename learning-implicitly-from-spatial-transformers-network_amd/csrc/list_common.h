@@ -363,6 +363,7 @@ struct ScatterParams {
   GatherParams g;             // points (x_hi/x_lo unused)
   const void* dx; int dx_f16; // [rows][Kp]
   const float* scale;         // [0] = s, [1] = 1/s
+  int forked;                 // the adjoint forms run side by side on auxiliary streams
 };
 // buffers of the voxel-side gather (bwd_scatter_kernels.hip); bins == nullptr disables it
 constexpr int64_t kVoxGatherMaxBins = 4194304;      // cells (B * D * H * W) a level may have

@@ -37,7 +37,8 @@ for it in range(steps + 2):
     sdf, ctx = hip.sdf_query(inp["query"], inp["trans_mat"], img, vox, packed, precision=precision,
                              save_for_backward=True)
     ev.record(e[2])
-    out = hip.sdf_query_backward(ctx, gsdf, packed_b, stage_events=arr)
+    out = hip.sdf_query_backward(ctx, gsdf, packed_b, stage_events=arr,
+                                 overlap=os.environ.get("LIST_BWD_OVERLAP", "1") == "1")
     ev.record(e[3])
     lv = hip.img_map_grad_to_levels(out["img_map"], inp["img_maps"])
     e4 = ev.create(); ev.record(e4)
