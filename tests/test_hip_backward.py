@@ -157,6 +157,9 @@ def test_backward_is_independent_of_point_order_and_partial_outputs(hip, golden_
     assert set(only_mlp) == {"d_" + k for k in c["weights"]}
     for k in only_mlp:
         assert rel_max(only_mlp[k], a[k]) < 1e-5, k
+    _, inline = hip_gradients(hip, c, g["grad_sdf"], "bf16x3", want=dict(overlap=False))   # no auxiliary streams
+    for k in a:
+        assert rel_max(inline[k], a[k]) < 1e-5, k
     _, only_maps = hip_gradients(hip, c, g["grad_sdf"], "bf16x3", want=dict(want_mlp=False))
     for k in only_maps:
         assert rel_max(only_maps[k], a[k]) < 1e-5, k
