@@ -206,7 +206,9 @@ int list_gather_features_fwd(const ListQueryArgs* args, float* out, void* stream
  * list_gemm_nt -- test/diagnostic entry for the MFMA kernel used by the MLP:
  * out[M][N] = act(A[M][K] . W[N][K]^T + bias), A and W given as bf16 hi/lo planes
  * (lo may be NULL with LIST_PREC_BF16; with LIST_PREC_FP16 the hi planes hold fp16 and lo is
- * ignored).  M % 256 == 0, N % 256 == 0, K % 64 == 0.
+ * ignored).  M % 256 == 0, N % 256 == 0, K % 64 == 0.  relu: bit 0 = apply ReLU; bit 1 = force the plain
+ * 2-stage loop instead of the ping-pong schedule that long-K single-plane products take (the two are
+ * bit-identical by construction: same accumulation order -- the tests use this as a race detector).
  */
 int list_gemm_nt(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo,
                  const float* bias, float* out, int32_t M, int32_t N, int32_t K, int32_t relu,

@@ -143,98 +143,10 @@ __device__ __forceinline__ void store8_planes(unsigned short* __restrict__ hi, u
   if (!FP16 && lo) *(uint4*)(lo + off) = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
-// TERMS = 3: bf16 hi/lo split (3 products); TERMS = 1: single plane, bf16 (FP16 = 0) or fp16 (FP16 = 1)
-template <int TERMS, int EPI, int FP16>
-__global__ __launch_bounds__(512, 2) void k_gemm_nt(GemmParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-
-  // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
-  // run of tiles so the N-tiles of one M-tile (same A rows) run on one L2.  Bijective for any grid.
-  const int tiles_n = p.N / BN;
-  const int ntiles = (p.M / BM) * tiles_n;
-  const int tile = xcd_contiguous_block(blockIdx.x, ntiles);
-  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  // fragment addresses: lane l holds A[row l&31][k = 8*(l>>5) .. +7] of each 32x16 operand block
-  using P = Pipe<TERMS>;
-  const int frow = lane & 31, fh = lane >> 5;
-  const int fswz = P::swz(frow);                       // tile row offsets are multiples of 32
-  const int a_row_off = (wm * 128 + frow) * P::kRowBytes;
-  const int w_row_off = (wn * 64 + frow) * P::kRowBytes;
-
-  const int nk = p.K / P::BK;
-#pragma unroll
-  for (int s = 0; s < P::kAhead; ++s)
-    if (s < nk) stage_tiles<TERMS>(p, smem + s * P::kStageBytes, m0, n0, s * P::kRowBytes, wave, lane);
-  for (int t = 0; t < nk; ++t) {
-    // stage t must have landed; stages t+1 .. t+kAhead-1 (those that exist) may stay in flight
-    const int younger = min(P::kAhead - 1, nk - 1 - t);
-    if (younger >= 2) wait_vmcnt<2 * P::kLoadsPerStage>();
-    else if (younger == 1) wait_vmcnt<P::kLoadsPerStage>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-#ifndef LIST_GEMM_NO_LOAD
-    if (t + P::kAhead < nk)
-      stage_tiles<TERMS>(p, smem + ((t + P::kAhead) % P::kStages) * P::kStageBytes, m0, n0,
-                         (t + P::kAhead) * P::kRowBytes, wave, lane);
-#endif
-    const char* cur = smem + (t % P::kStages) * P::kStageBytes;
-    // Register double-buffered fragments: the ds_reads of k16-step s2+1 are issued ahead of the MFMAs
-    // of step s2 (written as one buffer, hipcc reuses four fragment registers and exposes an
-    // lgkmcnt(0) round trip every four MFMAs; sched_group_barrier pinning measured no further gain).
-    constexpr int NS = P::BK / 16;
-    bf16x8 ah[2][4], al[2][4], wh[2][2], wl[2][2];
-    auto load_frags = [&](int s2, int buf) {
-      const int coff = ((2 * s2 + fh) ^ fswz) << 4;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ah[buf][i] = *(const bf16x8*)(cur + a_row_off + i * 32 * P::kRowBytes + coff);
-        if (TERMS == 3)
-          al[buf][i] = *(const bf16x8*)(cur + P::kPlaneBytes + a_row_off + i * 32 * P::kRowBytes + coff);
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        wh[buf][j] = *(const bf16x8*)(cur + P::kWOff + w_row_off + j * 32 * P::kRowBytes + coff);
-        if (TERMS == 3)
-          wl[buf][j] = *(const bf16x8*)(cur + P::kWOff + P::kPlaneBytes + w_row_off + j * 32 * P::kRowBytes + coff);
-      }
-    };
-#ifdef LIST_GEMM_NO_FRAGS
-    continue;        // ablation: LDS-DMA stream + barrier only
-#endif
-    load_frags(0, 0);
-#pragma unroll
-    for (int s2 = 0; s2 < NS; ++s2) {
-      const int b = s2 & 1;
-      if (s2 + 1 < NS) load_frags(s2 + 1, b ^ 1);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if (TERMS == 3) {
-            acc[i][j] = mfma<0>(al[b][i], wh[b][j], acc[i][j]);
-            acc[i][j] = mfma<0>(ah[b][i], wl[b][j], acc[i][j]);
-          }
-#ifdef LIST_GEMM_NO_MFMA
-          asm volatile("" ::"v"(ah[b][i]), "v"(wh[b][j]));
-#else
-          acc[i][j] = mfma<FP16>(ah[b][i], wh[b][j], acc[i][j]);
-#endif
-        }
-    }
-  }
-
+// ---- epilogues of the 32x32 kernels ------------------------------------------------------------------------
+template <int EPI, int FP16>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[4][2], char* smem, int m0, int n0,
+                                              int wm, int wn, int wave, int lane) {
   // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const int col_in = lane & 31, row_in = 4 * (lane >> 5);
   if (EPI == EPI_MASK_SPLIT) {
@@ -356,6 +268,216 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(GemmParams p) {
       }
     }
   }
+}
+
+// TERMS = 3: bf16 hi/lo split (3 products); TERMS = 1: single plane, bf16 (FP16 = 0) or fp16 (FP16 = 1)
+template <int TERMS, int EPI, int FP16>
+__global__ __launch_bounds__(512, 2) void k_gemm_nt(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
+  // run of tiles so the N-tiles of one M-tile (same A rows) run on one L2.  Bijective for any grid.
+  const int tiles_n = p.N / BN;
+  const int ntiles = (p.M / BM) * tiles_n;
+  const int tile = xcd_contiguous_block(blockIdx.x, ntiles);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment addresses: lane l holds A[row l&31][k = 8*(l>>5) .. +7] of each 32x16 operand block
+  using P = Pipe<TERMS>;
+  const int frow = lane & 31, fh = lane >> 5;
+  const int fswz = P::swz(frow);                       // tile row offsets are multiples of 32
+  const int a_row_off = (wm * 128 + frow) * P::kRowBytes;
+  const int w_row_off = (wn * 64 + frow) * P::kRowBytes;
+
+  const int nk = p.K / P::BK;
+#pragma unroll
+  for (int s = 0; s < P::kAhead; ++s)
+    if (s < nk) stage_tiles<TERMS>(p, smem + s * P::kStageBytes, m0, n0, s * P::kRowBytes, wave, lane);
+  for (int t = 0; t < nk; ++t) {
+    // stage t must have landed; stages t+1 .. t+kAhead-1 (those that exist) may stay in flight
+    const int younger = min(P::kAhead - 1, nk - 1 - t);
+    if (younger >= 2) wait_vmcnt<2 * P::kLoadsPerStage>();
+    else if (younger == 1) wait_vmcnt<P::kLoadsPerStage>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+#ifndef LIST_GEMM_NO_LOAD
+    if (t + P::kAhead < nk)
+      stage_tiles<TERMS>(p, smem + ((t + P::kAhead) % P::kStages) * P::kStageBytes, m0, n0,
+                         (t + P::kAhead) * P::kRowBytes, wave, lane);
+#endif
+    const char* cur = smem + (t % P::kStages) * P::kStageBytes;
+    // Register double-buffered fragments: the ds_reads of k16-step s2+1 are issued ahead of the MFMAs
+    // of step s2 (written as one buffer, hipcc reuses four fragment registers and exposes an
+    // lgkmcnt(0) round trip every four MFMAs; sched_group_barrier pinning measured no further gain).
+    constexpr int NS = P::BK / 16;
+    bf16x8 ah[2][4], al[2][4], wh[2][2], wl[2][2];
+    auto load_frags = [&](int s2, int buf) {
+      const int coff = ((2 * s2 + fh) ^ fswz) << 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ah[buf][i] = *(const bf16x8*)(cur + a_row_off + i * 32 * P::kRowBytes + coff);
+        if (TERMS == 3)
+          al[buf][i] = *(const bf16x8*)(cur + P::kPlaneBytes + a_row_off + i * 32 * P::kRowBytes + coff);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        wh[buf][j] = *(const bf16x8*)(cur + P::kWOff + w_row_off + j * 32 * P::kRowBytes + coff);
+        if (TERMS == 3)
+          wl[buf][j] = *(const bf16x8*)(cur + P::kWOff + P::kPlaneBytes + w_row_off + j * 32 * P::kRowBytes + coff);
+      }
+    };
+#ifdef LIST_GEMM_NO_FRAGS
+    continue;        // ablation: LDS-DMA stream + barrier only
+#endif
+    load_frags(0, 0);
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) {
+      const int b = s2 & 1;
+      if (s2 + 1 < NS) load_frags(s2 + 1, b ^ 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (TERMS == 3) {
+            acc[i][j] = mfma<0>(al[b][i], wh[b][j], acc[i][j]);
+            acc[i][j] = mfma<0>(ah[b][i], wl[b][j], acc[i][j]);
+          }
+#ifdef LIST_GEMM_NO_MFMA
+          asm volatile("" ::"v"(ah[b][i]), "v"(wh[b][j]));
+#else
+          acc[i][j] = mfma<FP16>(ah[b][i], wh[b][j], acc[i][j]);
+#endif
+        }
+    }
+  }
+
+  gemm_epilogue<EPI, FP16>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+}
+
+// ---- ping-pong schedule (single-plane operands, BK = 64) -----------------------------------------------------------
+// Same tile, LDS image, swizzle and epilogues as k_gemm_nt; a different schedule, after the guide's 256^2 8-phase
+// template.  A K-tile is four phases, one 64 x 32 quadrant of the wave's 128 x 64 outputs each (8 MFMAs over K = 64):
+//   p0: read A(i0,i1), W(j0) -> q(i01,j0)   p1: read W(j1) -> q(i01,j1)   p2: read A(i2,i3) -> q(i23,j1)   p3: -> q(i23,j0)
+// Every phase is [READ: ds_reads + ONE quarter of the next K-tile's LDS-DMA staging | s_barrier | MFMAs | s_barrier],
+// and the two wave groups (wm = 0 / 1: the two waves of every SIMD) run ONE barrier apart, so that on each SIMD one
+// wave reads LDS and issues loads while the other issues MFMAs.  Waits are counted: vmcnt(4) at the end of every READ
+// section keeps the two youngest quarters in flight across the barriers, the loop never drains to 0.  Ordering:
+// a quarter staged in phase k is complete for every wave after the waits of phase k+2 and the barrier behind the
+// later group's wait, i.e. it is first read in phase k+3 -- so the quarters are staged in the order
+// [A first halves, W first halves] (read in the next tile's p0), [W second halves] (p1), [A second halves] (p2);
+// a quarter is re-staged four phases after its last read.
+__device__ __forceinline__ int a_quarter_row(int q, int half) { return (q >> 3) * 128 + half * 64 + (q & 7) * 8; }
+__device__ __forceinline__ int w_quarter_row(int q, int half) { return (q >> 2) * 64 + half * 32 + (q & 3) * 8; }
+
+template <int EPI, int FP16>
+__global__ __launch_bounds__(512, 2) void k_gemm_nt_pp(GemmParams p) {
+  using P = Pipe<1>;
+  static_assert(P::BK == 64 && P::kRowBytes == 128, "single-plane pipeline");
+  __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int tiles_n = p.N / BN;
+  const int ntiles = (p.M / BM) * tiles_n;
+  const int tile = xcd_contiguous_block(blockIdx.x, ntiles);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int frow = lane & 31, fh = lane >> 5;
+  const int fswz = P::swz(frow);
+  const int a_row_off = (wm * 128 + frow) * P::kRowBytes;
+  const int w_row_off = (wn * 64 + frow) * P::kRowBytes;
+  const int64_t ld = (int64_t)p.K * 2;
+  const int nk = p.K / P::BK;
+
+  // one staging quarter = 16 pieces of 1 KB (8 rows of 128 B); this wave moves pieces 2 wave and 2 wave + 1
+  auto stage_quarter = [&](char* sbase, int kbyte, int quarter) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int q = 2 * wave + r;
+      const bool is_a = quarter == 0 || quarter == 3;
+      const int row0 = is_a ? a_quarter_row(q, quarter == 3) : w_quarter_row(q, quarter == 2);
+      const int row = row0 + lane / 8;
+      const int chunk = (lane % 8) ^ P::swz(row);
+      const char* g = (is_a ? p.a_hi + (int64_t)(m0 + row) * ld : p.w_hi + (int64_t)(n0 + row) * ld) + kbyte + chunk * 16;
+      glds16(g, sbase + (is_a ? 0 : P::kWOff) + row0 * P::kRowBytes);
+    }
+  };
+  auto frag = [&](const char* cur, int plane_off, int row_off, int t32, int s2) -> bf16x8 {
+    return *(const bf16x8*)(cur + plane_off + row_off + t32 * 32 * P::kRowBytes + (((2 * s2 + fh) ^ fswz) << 4));
+  };
+
+  // prologue: the whole first K-tile, visible to everybody; then the second wave group falls one barrier behind
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) stage_quarter(smem, 0, qd);
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();
+
+  bf16x8 a[2][4], w[2][4];            // a[i & 1][s2]: A fragments of the current i-pair; w[j][s2]
+  for (int t = 0; t < nk; ++t) {
+    const char* cur = smem + (t & 1) * P::kStageBytes;
+    char* nxt = smem + ((t + 1) & 1) * P::kStageBytes;
+    const bool more = t + 1 < nk;
+    const int kb = (t + 1) * P::kRowBytes;
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+      // ---- READ section: this phase's fragments, one quarter of the next K-tile, the counted wait
+      if (ph == 0) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+          w[0][s2] = frag(cur, P::kWOff, w_row_off, 0, s2);
+          a[0][s2] = frag(cur, 0, a_row_off, 0, s2);
+          a[1][s2] = frag(cur, 0, a_row_off, 1, s2);
+        }
+      } else if (ph == 1) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) w[1][s2] = frag(cur, P::kWOff, w_row_off, 1, s2);
+      } else if (ph == 2) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+          a[0][s2] = frag(cur, 0, a_row_off, 2, s2);
+          a[1][s2] = frag(cur, 0, a_row_off, 3, s2);
+        }
+      }
+      if (more) {
+        stage_quarter(nxt, kb, ph);
+        wait_vmcnt<4>();               // my loads of the quarter staged two phases ago have landed
+      } else {
+        wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_s_barrier();
+      // ---- MFMA section: one 64 x 32 quadrant over the whole K-tile
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int i0 = ph < 2 ? 0 : 2, j = (ph == 0 || ph == 3) ? 0 : 1;
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        acc[i0][j] = mfma<FP16>(a[0][s2], w[j][s2], acc[i0][j]);
+        acc[i0 + 1][j] = mfma<FP16>(a[1][s2], w[j][s2], acc[i0 + 1][j]);
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();     // the first group waits for the second to catch up
+  gemm_epilogue<EPI, FP16>(p, acc, smem, m0, n0, wm, wn, wave, lane);
 }
 
 // ---- the same kernel on the 16x16x32 MFMA shape -----------------------------------------------------
@@ -522,8 +644,19 @@ static hipError_t launch_one(const GemmParams& p, hipStream_t s) {
   // the cheaper row reduction of the fused fc_2 + fc_out epilogue (0.045 vs 0.058 ms)
   if constexpr (EPI == EPI_RELU_DOT)
     hipLaunchKernelGGL((k_gemm_nt16<TERMS, EPI, FP16>), dim3(ntiles), dim3(512), 0, s, p);
-  else
+  else {
+#ifndef LIST_GEMM_NO_PINGPONG
+    // the ping-pong schedule pays from ~16 K-tiles on (fc_0: 57; measured -6 %); shorter K (fc_1, dH, dX: 4-8
+    // K-tiles) is dominated by its prologue and stagger and stays on the plain 2-stage loop (+4 % there)
+    if constexpr (TERMS == 1) {
+      if (p.K >= 1024 && !p.plain_loop) {
+        hipLaunchKernelGGL((k_gemm_nt_pp<EPI, FP16>), dim3(ntiles), dim3(512), 0, s, p);
+        return hipGetLastError();
+      }
+    }
+#endif
     hipLaunchKernelGGL((k_gemm_nt<TERMS, EPI, FP16>), dim3(ntiles), dim3(512), 0, s, p);
+  }
   return hipGetLastError();
 }
 

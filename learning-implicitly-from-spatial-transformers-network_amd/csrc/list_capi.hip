@@ -723,7 +723,8 @@ int list_gemm_nt(const void* a_hi, const void* a_lo, const void* w_hi, const voi
   memset(&gp, 0, sizeof(gp));
   gp.a_hi = (const char*)a_hi; gp.a_lo = (const char*)a_lo;
   gp.w_hi = (const char*)w_hi; gp.w_lo = (const char*)w_lo;
-  gp.bias = bias; gp.M = M; gp.N = N; gp.K = K; gp.out_f32 = out; gp.relu = relu;
+  gp.bias = bias; gp.M = M; gp.N = N; gp.K = K; gp.out_f32 = out; gp.relu = relu & 1;
+  gp.plain_loop = (relu & 2) ? 1 : 0;
   gp.fmt = precision == LIST_PREC_FP16 ? FMT_FP16 : FMT_BF16_SPLIT;
   hipError_t e = launch_gemm(gp, precision == LIST_PREC_BF16X3 ? 3 : 1, EPI_F32, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "gemm launch");

@@ -304,6 +304,7 @@ struct GemmParams {
   int fmt;                                                   // FMT_BF16_SPLIT or FMT_FP16
   const unsigned short* mask; int ldmask;                    // EPI_MASK_SPLIT: keep acc where mask plane != 0
   void* dx; int dx_f16; int n_store;                         // EPI_DX: [M][ldo] fp16/fp32, columns < n_store
+  int plain_loop;                                            // diagnostics: never take the ping-pong schedule
 };
 
 // EPI_MASK_SPLIT: out = acc where the saved activation is positive (ReLU backward), no bias;

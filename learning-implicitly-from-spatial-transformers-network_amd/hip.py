@@ -635,8 +635,9 @@ def to_fp16(x):
     return out
 
 
-def gemm_nt(a, w, bias=None, relu=False, precision="bf16x3"):
-    """Diagnostic: out[M,N] = act(a[M,K] @ w[N,K]^T + bias) through the MLP's MFMA kernel."""
+def gemm_nt(a, w, bias=None, relu=False, precision="bf16x3", plain_loop=False):
+    """Diagnostic: out[M,N] = act(a[M,K] @ w[N,K]^T + bias) through the MLP's MFMA kernel.
+    plain_loop: force the 2-stage loop where the ping-pong schedule would be taken."""
     lib = load()
     M, K = a.shape
     N = w.shape[0]
@@ -651,5 +652,6 @@ def gemm_nt(a, w, bias=None, relu=False, precision="bf16x3"):
     with torch.cuda.device(a.device):
         _check(lib.list_gemm_nt(a_hi.data_ptr(), a_lo.data_ptr(), w_hi.data_ptr(), w_lo.data_ptr(),
                                 b.data_ptr() if b is not None else None, out.data_ptr(), M, N, K,
-                                int(relu), PRECISIONS[precision], _stream()), "list_gemm_nt")
+                                int(relu) | (2 if plain_loop else 0), PRECISIONS[precision], _stream()),
+               "list_gemm_nt")
     return out

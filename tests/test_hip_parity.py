@@ -82,6 +82,20 @@ def test_gemm_kernel_matches_fp64(hip, M, N, K):
     assert (np.abs(out2 - ref) / scale).max() < 1.5e-3
 
 
+def test_pingpong_schedule_is_bit_identical_to_the_plain_loop(hip):
+    """Long-K single-plane products run the ping-pong schedule (two wave groups one barrier apart, LDS-DMA
+    quarters in flight behind counted vmcnt waits).  It accumulates in the same order as the plain 2-stage
+    loop, so any difference is a race: many shapes x repetitions must agree bit for bit."""
+    for rep in range(6):
+        for (M, N, K) in [(256, 256, 1024), (512, 512, 3648), (2048, 256, 2048), (1024, 512, 1088)]:
+            a = synth.normalish(100 + rep, (M, K))
+            w = synth.uniform(200 + rep, (N, K), -0.05, 0.05)
+            for prec in ("fp16", "bf16"):
+                x = hip.gemm_nt(dev(a), dev(w), None, precision=prec)
+                y = hip.gemm_nt(dev(a), dev(w), None, precision=prec, plain_loop=True)
+                assert torch.equal(x, y), (rep, M, N, K, prec)
+
+
 def test_gemm_kernel_identity_asymmetric(hip):
     """A = I against an asymmetric W catches a transposed C-write or a wrong k-order."""
     K = N = 256
