@@ -14,6 +14,8 @@
 // slots of the 256-B bank row.
 // Epilogues: bias+ReLU+bf16 split store (hidden layers), fp32 store (tests), and
 // bias+ReLU+dot(w3)+b3 -> sdf (fc_2 and fc_out fused; needs N == 256).
+#include <type_traits>
+
 #include "list_common.h"
 
 namespace list {
@@ -371,14 +373,23 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(GemmParams p) {
 //   p0: read A(i0,i1), W(j0) -> q(i01,j0)   p1: read W(j1) -> q(i01,j1)   p2: read A(i2,i3) -> q(i23,j1)   p3: -> q(i23,j0)
 // Every phase is [READ: ds_reads + ONE quarter of the next K-tile's LDS-DMA staging | s_barrier | MFMAs | s_barrier],
 // and the two wave groups (wm = 0 / 1: the two waves of every SIMD) run ONE barrier apart, so that on each SIMD one
-// wave reads LDS and issues loads while the other issues MFMAs.  Waits are counted: vmcnt(4) at the end of every READ
-// section keeps the two youngest quarters in flight across the barriers, the loop never drains to 0.  Ordering:
-// a quarter staged in phase k is complete for every wave after the waits of phase k+2 and the barrier behind the
-// later group's wait, i.e. it is first read in phase k+3 -- so the quarters are staged in the order
-// [A first halves, W first halves] (read in the next tile's p0), [W second halves] (p1), [A second halves] (p2);
-// a quarter is re-staged four phases after its last read.
+// wave reads LDS and issues loads while the other issues MFMAs.  Staging runs kLead phases ahead of the phase that
+// owns the quarter (quarter g = 4 tile + {A first halves, W first halves, W second halves, A second halves} is issued
+// in phase g - kLead) and the wait is a counted vmcnt(2 (kLead - 2)) at the end of every READ section: the kLead - 2
+// youngest quarters stay in flight across the barriers, the loop never drains to 0.  (Measured: -2 .. -6 % against the
+// 2-stage loop depending on the device; kLead 4, 5 and 6 within 1 %: the loop is bound by LDS / LDS-DMA throughput,
+// not by load latency.)
+// Ordering: every wave has waited for its loads of quarter g by phase g-2, the barrier behind the later group's
+// wait makes it complete for all, and it is first read in phase g-1 at the earliest (W first halves; A first g,
+// W second g-1, A second g-1).  The 8 quarter slots are the two K-tile buffers; a slot is re-staged two phases
+// after its last read or later.
 __device__ __forceinline__ int a_quarter_row(int q, int half) { return (q >> 3) * 128 + half * 64 + (q & 7) * 8; }
 __device__ __forceinline__ int w_quarter_row(int q, int half) { return (q >> 2) * 64 + half * 32 + (q & 3) * 8; }
+
+#ifndef LIST_PP_LEAD
+#define LIST_PP_LEAD 4
+#endif
+constexpr int kLead = LIST_PP_LEAD;      // phases between the issue of a staging quarter and the phase that owns it (4..6)
 
 template <int EPI, int FP16>
 __global__ __launch_bounds__(512, 2) void k_gemm_nt_pp(GemmParams p) {
@@ -425,22 +436,24 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_pp(GemmParams p) {
     return *(const bf16x8*)(cur + plane_off + row_off + t32 * 32 * P::kRowBytes + (((2 * s2 + fh) ^ fswz) << 4));
   };
 
-  // prologue: the whole first K-tile, visible to everybody; then the second wave group falls one barrier behind
+  // prologue: quarters 0 .. kLead-1; the first K-tile must be complete for everybody; then the second wave
+  // group falls one barrier behind
 #pragma unroll
-  for (int qd = 0; qd < 4; ++qd) stage_quarter(smem, 0, qd);
-  wait_vmcnt<0>();
+  for (int g = 0; g < kLead; ++g)
+    if (g / 4 < nk) stage_quarter(smem + ((g / 4) & 1) * P::kStageBytes, (g / 4) * P::kRowBytes, g & 3);
+  if (nk > 1) wait_vmcnt<2 * (kLead - 4)>(); else wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();
+  const int last_quarter = 4 * nk - 1;
 
   bf16x8 a[2][4], w[2][4];            // a[i & 1][s2]: A fragments of the current i-pair; w[j][s2]
-  for (int t = 0; t < nk; ++t) {
+  // one K-tile; STEADY: every phase still has kLead - 2 younger quarters in flight (no branches in the body)
+  auto k_tile = [&](int t, auto steady) {
+    constexpr bool STEADY = decltype(steady)::value;
     const char* cur = smem + (t & 1) * P::kStageBytes;
-    char* nxt = smem + ((t + 1) & 1) * P::kStageBytes;
-    const bool more = t + 1 < nk;
-    const int kb = (t + 1) * P::kRowBytes;
 #pragma unroll
     for (int ph = 0; ph < 4; ++ph) {
-      // ---- READ section: this phase's fragments, one quarter of the next K-tile, the counted wait
+      // ---- READ section: this phase's fragments, one staging quarter kLead phases ahead, the counted wait
       if (ph == 0) {
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {
@@ -458,11 +471,20 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_pp(GemmParams p) {
           a[1][s2] = frag(cur, 0, a_row_off, 3, s2);
         }
       }
-      if (more) {
-        stage_quarter(nxt, kb, ph);
-        wait_vmcnt<4>();               // my loads of the quarter staged two phases ago have landed
+      // quarter g = k + kLead of the sequence (k = 4 t + ph)
+      const int tt = t + (ph + kLead) / 4;
+      const int sq = (ph + kLead) & 3;
+      if (STEADY) {
+        stage_quarter(smem + (tt & 1) * P::kStageBytes, tt * P::kRowBytes, sq);
+        wait_vmcnt<2 * (kLead - 2)>();     // my loads of every quarter up to k + 2 have landed
       } else {
-        wait_vmcnt<0>();
+        if (tt < nk) stage_quarter(smem + (tt & 1) * P::kStageBytes, tt * P::kRowBytes, sq);
+        const int beyond = last_quarter - (4 * t + ph + 2);        // quarters issued beyond k + 2
+        if (beyond >= 4) wait_vmcnt<2 * (kLead - 2 < 4 ? kLead - 2 : 4)>();
+        else if (beyond == 3) wait_vmcnt<2 * (kLead - 2 < 3 ? kLead - 2 : 3)>();
+        else if (beyond == 2) wait_vmcnt<4>();
+        else if (beyond == 1) wait_vmcnt<2>();
+        else wait_vmcnt<0>();
       }
       __builtin_amdgcn_s_barrier();
       // ---- MFMA section: one 64 x 32 quadrant over the whole K-tile
@@ -475,7 +497,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_pp(GemmParams p) {
       }
       __builtin_amdgcn_s_barrier();
     }
-  }
+  };
+  int t = 0;
+  for (; t + 3 <= nk; ++t) k_tile(t, std::true_type());       // tiles 0 .. nk-3
+  for (; t < nk; ++t) k_tile(t, std::false_type());           // the last two: fewer quarters left to fly
   if (wm == 0) __builtin_amdgcn_s_barrier();     // the first group waits for the second to catch up
   gemm_epilogue<EPI, FP16>(p, acc, smem, m0, n0, wm, wn, wave, lane);
 }
