@@ -288,8 +288,9 @@ def roofline_of(kernel_ms, table, precision):
         traffic = json.load(open(tf)).get(precision, {}).get(dom)
     if bound == "mfma":
         ach = units / secs / 1e12
-        return {"kernel": {"fc_0": "k_gemm_nt (fc_0 + ReLU)", "fc_1": "k_gemm_nt (fc_1 + ReLU)",
-                           "fc_2_out": "k_gemm_nt (fc_2 + ReLU + fc_out)"}[dom],
+        fc0 = "k_gemm_nt (fc_0 + ReLU)" if precision == "bf16x3" else "k_gemm_nt_pp (fc_0 + ReLU)"
+        return {"kernel": {"fc_0": fc0, "fc_1": "k_gemm_nt (fc_1 + ReLU)",
+                           "fc_2_out": "k_gemm_nt16 (fc_2 + ReLU + fc_out)"}[dom],
                 "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "launch_ms": kernel_ms[dom],
                 "algorithmic_flop_per_launch": units,

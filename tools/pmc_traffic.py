@@ -25,7 +25,9 @@ def kernel_key(name, grid, seq):
     if not m:
         return None
     k, t = m.group(1), (m.group(2) or "")
-    if k == "k_gemm_nt":
+    if k == "k_gemm_nt_pp":                   # long-K single-plane products: fc_0
+        return "fc_0"
+    if k in ("k_gemm_nt", "k_gemm_nt16"):
         epi = t.strip("<>").split(",")[1].strip()
         if epi == "2":
             return "fc_2_out"
