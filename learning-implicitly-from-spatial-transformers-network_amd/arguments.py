@@ -64,6 +64,7 @@ def build_parser():
     p.add_argument("--h5_dir", default="./Datasets/shapenet/sampled_points/")
     p.add_argument("--cam_dir", default="./Datasets/shapenet/images/")
     p.add_argument("--image_dir", default="./Datasets/shapenet/images/")
+    p.add_argument("--split_dir", default="./data/DISN_split/", help="{cat}_{train,test}.lst shape-id lists")
     p.add_argument("--catlist", type=str, nargs="+",
                    default=["03001627", "02691156", "02828884", "02933112", "03211117", "03636649",
                             "03691459", "04090263", "04256520", "04379243", "04530566", "02958343",

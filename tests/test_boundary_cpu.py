@@ -20,7 +20,7 @@ def test_get_class_resolves_reference_names():
     assert utils.get_class("network.models.LIST").__name__ == "LIST"
     assert utils.get_class("network.executors.LIST").__name__ == "LIST"
     assert utils.get_class("network.models.CoarseNet").__name__ == "CoarseNet"
-    assert utils.get_class("datasets.Datasets.IM2SDF").__name__ == "SyntheticIM2SDF"
+    assert utils.get_class("datasets.Datasets.IM2SDF").__name__ == "IM2SDF"
     with pytest.raises(ImportError):
         utils.get_class("network.models.Nope")
 
@@ -118,10 +118,89 @@ def test_synthetic_datasets_have_reference_keys(cfg):
     item = utils.get_class("datasets.Datasets.SyntheticIM2SDF")(cfg2, "train")[0]
     assert set(item) == {"rgb_image", "points", "values", "occ"}
     assert item["rgb_image"].shape == (3, 32, 32) and item["points"].shape == (200, 3)
-    assert item["values"].shape == (200,) and item["occ"].shape == (16, 16, 16)
+    assert item["values"].shape == (200,) and item["occ"].shape == (1, 16, 16, 16)
     assert float(item["points"].abs().max()) <= 0.5
     pf = utils.get_class("datasets.Datasets.SyntheticIM2PointFarthest")(cfg2, "train")[1]
     assert pf["pc"].shape == (5000, 3)
+
+
+def _write_shape(root, cat, shape, rng, n_views=2, img=24, with_occ=None):
+    """One shape in the reference's on-disk layout (datasets/Datasets.py:176-252), .npz standing in for .h5."""
+    from PIL import Image
+    rgb_dir = root / "images" / cat / shape / "easy"
+    h5_dir = root / "sampled_points" / cat / shape
+    rgb_dir.mkdir(parents=True), h5_dir.mkdir(parents=True)
+    pix = []
+    for v in range(n_views):
+        a = rng.randint(0, 256, (img, img, 4)).astype(np.uint8)
+        Image.fromarray(a, "RGBA").save(rgb_dir / f"{v:02d}.png")
+        pix.append(a)
+    sig = {f"query_points_sigma_{s}": rng.randn(50 + 10 * i, 4).astype(np.float32) * 0.1
+           for i, s in enumerate([0.003, 0.01, 0.07])}
+    np.savez(h5_dir / "sampled_points.npz", **sig)
+    pc = (rng.rand(5000, 3).astype(np.float32) - 0.5) * 0.8
+    np.savez(h5_dir / "farthest_pointclouds.npz", points_5000=pc)
+    if with_occ is not None:
+        np.savez(h5_dir / "occupancies.npz", **with_occ)
+    return pix, sig, pc
+
+
+def test_file_datasets_follow_the_reference_layout(tmp_path):
+    """the on-disk formats either side of the path (Datasets.py:140-304 and :56-137)."""
+    rng = np.random.RandomState(7)
+    split = tmp_path / "split"
+    split.mkdir()
+    cat = "03001627"
+    (split / f"{cat}_train.lst").write_text("aaa\nbbb\nmissing\n")
+    pix, sig, pc = _write_shape(tmp_path, cat, "aaa", rng)
+    cached = (rng.rand(16 ** 3) < 0.1).astype(np.uint8)
+    _write_shape(tmp_path, cat, "bbb", rng, with_occ={"res_16_points_5000": cached})
+    cfg = arguments.default_config(vox_res=16, sample_point_density=200, cuda=False, viewnum=2, catlist=[cat],
+                                   split_dir=str(split) + "/", image_dir=str(tmp_path / "images") + "/",
+                                   h5_dir=str(tmp_path / "sampled_points") + "/", coarse_point_density=5000)
+    ds = utils.get_class("datasets.Datasets.IM2SDF")(cfg, "train")
+    assert type(ds).__name__ == "FileIM2SDF" and len(ds) == 2           # 'missing' has no files and is skipped
+    counts = np.rint(np.asarray(cfg.sample_distribution) * 200).astype(int)
+    item = ds[0]
+    assert set(item) == {"rgb_image", "points", "values", "occ"}
+    assert item["points"].shape == (counts.sum(), 3) and item["values"].shape == (counts.sum(),)
+    assert item["occ"].shape == (1, 16, 16, 16) and item["rgb_image"].shape == (3, 24, 24)
+    # the sampler is RandomState(333) drawing rint(distribution * density) rows per sigma, in sigma order
+    ref_rng, rows = np.random.RandomState(333), []
+    for s, num in zip(cfg.sigmas, counts):
+        q = sig[f"query_points_sigma_{s}"]
+        rows.append(q[ref_rng.randint(0, q.shape[0], num)])
+    rows = np.concatenate(rows)
+    np.testing.assert_array_equal(item["points"].numpy(), rows[:, :3])
+    np.testing.assert_array_equal(item["values"].numpy(), rows[:, 3])
+    # image planes are in the reference reader's (cv2) order: blue first, alpha dropped, /255
+    planes = [np.ascontiguousarray(p[:, :, 2::-1].transpose(2, 0, 1)).astype(np.float32) / 255 for p in pix]
+    assert any(np.array_equal(item["rgb_image"].numpy(), p) for p in planes)
+    # occupancy: nearest grid cell of every coarse point, cached next to the samples under the reference's key
+    from scipy.spatial import cKDTree
+    grid = utils.create_grid_points_from_bounds(cfg.bb_min, cfg.bb_max, 16)
+    want = np.zeros(16 ** 3, np.float32)
+    want[cKDTree(grid).query(pc)[1]] = 1
+    np.testing.assert_array_equal(item["occ"].numpy().ravel(), want)
+    store = np.load(tmp_path / "sampled_points" / cat / "aaa" / "occupancies.npz")
+    np.testing.assert_array_equal(store["res_16_points_5000"], want.astype(np.uint8))
+    np.testing.assert_array_equal(ds[1]["occ"].numpy().ravel(), cached.astype(np.float32))   # cache wins
+    # the same grid the model builds from the same points on the device path (models.py:102-112)
+    net = utils.get_class("network.models.LIST")(cfg)
+    np.testing.assert_array_equal(net.create_occ(torch.from_numpy(pc)[None]).numpy().ravel(), want)
+
+    pf = utils.get_class("datasets.Datasets.IM2PointFarthest")(cfg, "train")
+    assert type(pf).__name__ == "FileIM2PointFarthest" and len(pf) == 2
+    np.testing.assert_array_equal(pf[0]["pc"].numpy(), pc)
+    img, pts = pf.get_testdata(cat, "aaa", 1)
+    assert img.shape == (1, 3, 24, 24) and pts.shape == (1, 5000, 3)
+    np.testing.assert_array_equal(img[0].numpy(), planes[1])
+    # batches collate into what the executors read
+    batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=2)))
+    assert batch["occ"].shape == (2, 1, 16, 16, 16) and batch["points"].shape == (2, counts.sum(), 3)
+    # without split lists the reference's names give the generated stand-ins
+    cfg2 = arguments.default_config(vox_res=16, cuda=False, split_dir=str(tmp_path / "nowhere") + "/")
+    assert type(utils.get_class("datasets.Datasets.IM2SDF")(cfg2, "train")).__name__ == "SyntheticIM2SDF"
 
 
 def test_train_entry_point_coarsenet_cpu_one_step(tmp_path):
