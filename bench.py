@@ -194,13 +194,13 @@ def run_train_step(precision, steps, warmup, inp, hip, ev):
     gsdf = torch.randn((B, N), generator=g, device=inp["query"].device) / B
     n_ev = hip.N_BWD_STAGES
     acc = np.zeros(n_ev - 1)
-    fwd_ms = adj_ms = bwd_ms = 0.0
+    fwd_ms = bwd_ms = 0.0
     grads = None
 
     def step(timed):
         nonlocal grads
         arr = (ctypes.c_void_p * n_ev)(*[ev.create() for _ in range(n_ev)]) if timed else None
-        e = [ev.create() for _ in range(4)] if timed else None
+        e = [ev.create() for _ in range(3)] if timed else None
         img = hip.prep_img_maps(inp["img_maps"], inp["map_size"], md)
         vox = hip.prep_vox_maps(inp["vox_maps"], md)
         packed = hip.prep_mlp_weights(inp["weights"], vox.channels, img.channels, precision)
@@ -209,10 +209,8 @@ def run_train_step(precision, steps, warmup, inp, hip, ev):
         sdf, ctx = hip.sdf_query(inp["query"], inp["trans_mat"], img, vox, packed, precision=precision,
                                  save_for_backward=True, clamp_hi=inp["clamp_hi"])
         if timed: ev.record(e[1])
-        out = hip.sdf_query_backward(ctx, gsdf, packed_b, stage_events=arr)
+        out = hip.sdf_query_backward(ctx, gsdf, packed_b, stage_events=arr, img_levels_like=inp["img_maps"])
         if timed: ev.record(e[2])
-        out["img_levels"] = hip.img_map_grad_to_levels(out["img_map"], inp["img_maps"])
-        if timed: ev.record(e[3])
         grads = out
         return arr, e
 
@@ -228,16 +226,15 @@ def run_train_step(precision, steps, warmup, inp, hip, ev):
             acc[s] += ev.elapsed_ms(ctypes.c_void_p(arr[s]), ctypes.c_void_p(arr[s + 1]))
         fwd_ms += ev.elapsed_ms(e[0], e[1])
         bwd_ms += ev.elapsed_ms(e[1], e[2])
-        adj_ms += ev.elapsed_ms(e[2], e[3])
     kernel_ms = dict(zip(hip.BWD_STAGE_NAMES, (acc / steps).tolist()))
-    kernel_ms["img_grad_to_levels"] = adj_ms / steps
     return {"precision": precision, "steps": steps, "ms_per_step": elapsed / steps * 1e3,
             "value": B * N * steps / elapsed, "unit": "query-points/s (forward + backward)",
-            "forward_query_ms": fwd_ms / steps, "backward_ms": (bwd_ms + adj_ms) / steps,
+            "forward_query_ms": fwd_ms / steps, "backward_ms": bwd_ms / steps,
             "kernel_ms": kernel_ms,
             "kernel_ms_note": "stage intervals on the main stream; dW0, the atomic and the LDS-window voxel levels "
-                              "run concurrently on two auxiliary streams, so the stages overlap and do not add up "
-                              "to backward_ms",
+                              "run concurrently on two auxiliary streams and the adjoint resize to the 5 encoder "
+                              "levels follows trans_mat_grad on the main stream inside the same call, so the stages "
+                              "overlap and do not add up to backward_ms",
             "outputs": "d fc_0..fc_out (reference layout), d 5 image maps, d 6 voxel maps, d trans_mat"}, grads
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LIST_ABI_VERSION 2
+#define LIST_ABI_VERSION 3
 
 #define LIST_N_IMG_LEVELS 5   /* ResEncoder feature maps, network/modules.py:1067 */
 #define LIST_N_VOX_LEVELS 6   /* VoxelEncoder2 feature maps, network/modules.py:425-442 */
@@ -271,6 +271,10 @@ typedef struct ListQueryGradArgs {
                                       /*   the LDS-window scatters and the gathers need different units, so they */
                                       /*   are forked onto these streams (event fork/join around them: the call  */
                                       /*   is still ordered on `stream` as a whole).  NULL: everything in order. */
+  const ListMap2D* grad_img_levels;   /* optional: LIST_N_IMG_LEVELS descriptors as list_img_map_grad_to_levels   */
+                                      /*   takes them.  The adjoint resize then runs inside this call, beside the */
+                                      /*   voxel scatters still in flight on the auxiliary streams (needs         */
+                                      /*   grad_img_map as the intermediate).  NULL: call it yourself afterwards. */
 } ListQueryGradArgs;
 
 enum ListBwdStage {

@@ -409,6 +409,17 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   if (a->B >= 0 && a->N >= 0 && (int64_t)a->B * a->N == 0) return LIST_OK;
   int rc = check_query_common(a, &L);
   if (rc != LIST_OK) return rc;
+  if (ga->grad_img_levels) {
+    if (!ga->grad_img_map) return fail(LIST_ERR_ARG, "grad_img_levels needs grad_img_map as its intermediate");
+    if (a->map_size > 320) return fail(LIST_ERR_SHAPE, "grad_img_levels: map_size=%d (need <= 320)", a->map_size);
+    int ct = 0;
+    for (int i = 0; i < LIST_N_IMG_LEVELS; ++i) {
+      const ListMap2D& m = ga->grad_img_levels[i];
+      if (m.C < 1 || m.H < 1 || m.W < 1) return fail(LIST_ERR_SHAPE, "grad_img_levels[%d]: bad descriptor", i);
+      ct += m.C;
+    }
+    if (ct != a->img_C) return fail(LIST_ERR_SHAPE, "grad_img_levels: channels sum to %d, the map has %d", ct, a->img_C);
+  }
   if (a->percep_feat && (ga->grad_img_map || ga->grad_trans_mat))
     return fail(LIST_ERR_ARG, "with percep_feat the perceptual gradient is grad_percep_feat, not grad_img_map/grad_trans_mat");
   if (!a->percep_feat && ga->grad_percep_feat)
@@ -469,6 +480,31 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   float* slab = (float*)(bwp + bw.slab);
   auto plane = [&](size_t off) { return (unsigned short*)(bwp + off); };
 
+  // optional fork/join onto the caller's auxiliary streams (see ListQueryGradArgs.aux_streams)
+  hipStream_t s_direct = s, s_window = s;
+  const bool forked = ga->aux_streams[0] && ga->aux_streams[1];
+  if (forked) { s_direct = (hipStream_t)ga->aux_streams[0]; s_window = (hipStream_t)ga->aux_streams[1]; }
+  auto hand_over = [&](hipStream_t from, hipStream_t to) -> hipError_t {      // `to` continues after `from`'s work so far
+    if (from == to) return hipSuccess;
+    hipEvent_t ev;
+    hipError_t err = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (err != hipSuccess) return err;
+    err = hipEventRecord(ev, from);
+    if (err == hipSuccess) err = hipStreamWaitEvent(to, ev, 0);
+    (void)hipEventDestroy(ev);                    // released once the wait has been satisfied
+    return err;
+  };
+  ScatterParams sp;
+  sp.g = make_gather(a, L, ws, 0, n_valid, crow);
+  sp.g.order = order;
+  const bool pix = !a->no_sort && !a->percep_feat && a->map_size * ((a->map_size + 3) / 4) <= kSortPixCells;
+  if (pix) { sp.g.order_img = (const int*)(fw + ws.order_img); sp.g.row_of = (const int*)(fw + ws.row_of); }
+  sp.dx = bwp + bw.dx; sp.dx_f16 = fp16 ? 1 : 0; sp.scale = scale; sp.forked = forked ? 1 : 0;
+  VoxGatherBuffers vb;
+  vb.keys = (int*)(bwp + bw.vs_keys); vb.bins = (int*)(bwp + bw.vs_bins); vb.sums = (int*)(bwp + bw.vs_sums);
+  vb.recs = bwp + bw.vs_recs; vb.mode = ga->vox_adjoint;
+  const ScatterStreams sst = {s, s_direct, s_window};
+
   mark(LIST_BWD_BEGIN);
   // --- head: scale, fc_2 re-evaluation (H3), dZ3, d fc_out ----------------------------------------------
   LIST_TRY(launch_grad_scale(ga->grad_sdf, P, fp16 ? 1 : 0, scale, ga->mlp.b3, colsum, s), "grad_scale launch");
@@ -492,20 +528,6 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   mark(LIST_BWD_HEAD);
 
   // one layer of the chain: weight gradient (TN), bias gradient, then the masked data gradient (NT)
-  // optional fork/join onto the caller's auxiliary streams (see ListQueryGradArgs.aux_streams)
-  hipStream_t s_direct = s, s_window = s;
-  const bool forked = ga->aux_streams[0] && ga->aux_streams[1];
-  if (forked) { s_direct = (hipStream_t)ga->aux_streams[0]; s_window = (hipStream_t)ga->aux_streams[1]; }
-  auto hand_over = [&](hipStream_t from, hipStream_t to) -> hipError_t {      // `to` continues after `from`'s work so far
-    if (from == to) return hipSuccess;
-    hipEvent_t ev;
-    hipError_t err = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-    if (err != hipSuccess) return err;
-    err = hipEventRecord(ev, from);
-    if (err == hipSuccess) err = hipStreamWaitEvent(to, ev, 0);
-    (void)hipEventDestroy(ev);                    // released once the wait has been satisfied
-    return err;
-  };
   auto wgrad = [&](size_t dz_hi, size_t dz_lo, int M, const char* act_hi, const char* act_lo, int N, int ldb,
                    const FeatLayout* layout, float* out, int ldo, hipStream_t s) -> hipError_t {
     if (!out) return hipSuccess;
@@ -576,15 +598,6 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   }
   mark(LIST_BWD_DGRAD0);
 
-  ScatterParams sp;
-  sp.g = make_gather(a, L, ws, 0, n_valid, crow);
-  sp.g.order = order;
-  const bool pix = !a->no_sort && !a->percep_feat && a->map_size * ((a->map_size + 3) / 4) <= kSortPixCells;
-  if (pix) { sp.g.order_img = (const int*)(fw + ws.order_img); sp.g.row_of = (const int*)(fw + ws.row_of); }
-  sp.dx = bwp + bw.dx; sp.dx_f16 = fp16 ? 1 : 0; sp.scale = scale; sp.forked = forked ? 1 : 0;
-  VoxGatherBuffers vb;
-  vb.keys = (int*)(bwp + bw.vs_keys); vb.bins = (int*)(bwp + bw.vs_bins); vb.sums = (int*)(bwp + bw.vs_sums);
-  vb.recs = bwp + bw.vs_recs; vb.mode = ga->vox_adjoint;
   // dX is ready on `s`.  From here the work is a DAG of stages bound by different units: dW0 (MFMA; needs only
   // dZ1 and X) and the LDS-window levels on one stream, the atomic-rate-bound levels on another, the gathers
   // (voxel-side gather, perceptual map, trans_mat) on `s`.  Without auxiliary streams: the same order, in line.
@@ -593,7 +606,6 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   LIST_TRY(wgrad(bw.dz1_hi, bw.dz1_lo, a->H1, fw + ws.x_hi, fw + ws.x_lo, L.Kp, L.Kp, &L, ga->mlp.w0, L.F, s_window),
            "dW0 launch");
   mark(LIST_BWD_WGRAD0);
-  const ScatterStreams sst = {s, s_direct, s_window};
   LIST_TRY(launch_scatter_vox(sp, L, *a, ga->grad_vox, vb, sst), "voxel scatter launch");
   mark(LIST_BWD_VOX);
   if (a->percep_feat) {
@@ -610,6 +622,9 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   if (pix && a->B > kSortImages) { sp.g.order_img = nullptr; sp.g.row_of = nullptr; bins_pix = nullptr; }
   LIST_TRY(launch_img_grad(sp, L, *a, bins_pix, nslots, bwp + bw.recs, ga->grad_img_map, ga->grad_trans_mat,
                            ga->stage_events, s), "image gradient launch");
+  if (ga->grad_img_levels)
+    LIST_TRY(launch_img_grad_to_levels(ga->grad_img_map, a->B, a->map_size, L.img_C, ga->grad_img_levels, s),
+             "img_grad_to_levels launch");
   LIST_TRY(hand_over(s_direct, s), "stream join");
   LIST_TRY(hand_over(s_window, s), "stream join");
 #undef LIST_TRY

@@ -84,7 +84,8 @@ class ListQueryGradArgs(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("stage_events", C.POINTER(C.c_void_p)), ("vox_adjoint", C.c_int32),
                 ("grad_percep_feat", C.c_void_p), ("gpf_sb", C.c_int64), ("gpf_sc", C.c_int64),
-                ("gpf_sn", C.c_int64), ("aux_streams", C.c_void_p * 2)]
+                ("gpf_sn", C.c_int64), ("aux_streams", C.c_void_p * 2),
+                ("grad_img_levels", C.POINTER(ListMap2D))]
 
 
 VOX_ADJOINT = {"auto": 0, "scatter": 1, "gather": 2}
@@ -438,12 +439,14 @@ def _aux(device):
 
 
 def sdf_query_backward(ctx, grad_sdf, packed_bwd, want_mlp=True, want_img=True, want_vox=True,
-                       want_trans=True, stage_events=None, vox_adjoint="auto", overlap=True):
+                       want_trans=True, stage_events=None, vox_adjoint="auto", overlap=True, img_levels_like=None):
     """Backward of sdf_query (list_sdf_query_bwd).  Returns a dict:
       'mlp'       : {fc_0.weight [H1,F,1], fc_0.bias, ..., fc_out.bias} (reference layouts)
       'img_map'   : gradient of the prepared perceptual map, float32 [B,ms,ms,Ct]
       'vox'       : per level float32 [B,D,H,W,C] (channels-last; .permute(0,4,1,2,3) is the NCDHW view)
       'trans_mat' : [B,4,3]
+      'img_levels': with img_levels_like (the encoder's 5 maps): their gradients, shaped and strided like them --
+                    the adjoint resize then runs inside the call, beside the voxel scatters (else: img_map_grad_to_levels)
     For a forward with percep_feat (VoxelDecoder2.forward's own form) 'img_map'/'trans_mat' are replaced by
       'percep_feat': [B,img_C,N], the gradient of the pre-pooled features."""
     lib = load()
@@ -478,6 +481,9 @@ def sdf_query_backward(ctx, grad_sdf, packed_bwd, want_mlp=True, want_img=True, 
     if want_img:
         out["img_map"] = torch.empty((B, a.map_size, a.map_size, a.img_C), **f32)
         ga.grad_img_map = out["img_map"].data_ptr()
+    if want_img and img_levels_like is not None:
+        maps, out["img_levels"] = _level_descriptors(img_levels_like, a.img_C)
+        ga.grad_img_levels = maps
     if want_trans:
         out["trans_mat"] = torch.empty((B, 4, 3), **f32)
         ga.grad_trans_mat = out["trans_mat"].data_ptr()
@@ -504,20 +510,28 @@ def sdf_query_backward(ctx, grad_sdf, packed_bwd, want_mlp=True, want_img=True, 
     return out
 
 
+def _level_descriptors(like, img_C):
+    """Fresh gradients shaped and strided like the encoder's maps + their ListMap2D descriptors."""
+    if len(like) != N_IMG_LEVELS:
+        raise RuntimeError(f"need {N_IMG_LEVELS} image levels, got {len(like)}")
+    maps = (ListMap2D * N_IMG_LEVELS)()
+    outs = []
+    for i, t in enumerate(like):
+        o = torch.empty_like(t, dtype=torch.float32)
+        outs.append(o)
+        maps[i] = ListMap2D(o.data_ptr(), o.shape[1], o.shape[2], o.shape[3], *o.stride())
+    if sum(o.shape[1] for o in outs) != img_C:
+        raise RuntimeError("channel counts of `like` do not add up to the prepared map's")
+    return maps, outs
+
+
 def img_map_grad_to_levels(grad_img_map, like):
     """Adjoint of prep_img_maps: gradient of the prepared map [B,ms,ms,Ct] -> one gradient per encoder
     level, shaped (and strided) like the tensors in `like`."""
     lib = load()
     g = _f32_cuda(grad_img_map, "grad_img_map").contiguous()
     B, ms = g.shape[0], g.shape[1]
-    maps = (ListMap2D * N_IMG_LEVELS)()
-    outs = []
-    for i, t in enumerate(like):
-        o = torch.empty_like(t)
-        outs.append(o)
-        maps[i] = ListMap2D(o.data_ptr(), o.shape[1], o.shape[2], o.shape[3], *o.stride())
-    if sum(o.shape[1] for o in outs) != g.shape[3]:
-        raise RuntimeError("channel counts of `like` do not add up to the prepared map's")
+    maps, outs = _level_descriptors(like, g.shape[3])
     with torch.cuda.device(g.device):
         _check(lib.list_img_map_grad_to_levels(g.data_ptr(), B, ms, maps, _stream()),
                "list_img_map_grad_to_levels")

@@ -102,10 +102,12 @@ class _SdfQueryHipFn(torch.autograd.Function):
         want_mlp = any(needs[i_mlp:])
         grad_out = _f32(grad_out)
         total, lead_parts = None, []
+        # one piece: the adjoint resize runs inside the call; a cut query sums the map gradient first (it is linear)
+        like = ctx.img_like if (len(ctx.pieces) == 1 and want_img and not percep) else None
         for n0, n1, qctx in ctx.pieces:
             out = hip.sdf_query_backward(qctx, grad_out[:, n0:n1], ctx.state["packed_bwd"](), want_mlp=want_mlp,
                                          want_img=(want_lead if percep else want_img), want_vox=want_vox,
-                                         want_trans=(want_lead and not percep))
+                                         want_trans=(want_lead and not percep), img_levels_like=like)
             if percep and want_lead:
                 lead_parts.append(out.pop("percep_feat"))
             if total is None:
@@ -127,7 +129,7 @@ class _SdfQueryHipFn(torch.autograd.Function):
         else:
             grads.append(total["trans_mat"].reshape(ctx.lead_shape) if want_lead else None)
         if want_img and not percep:
-            levels = hip.img_map_grad_to_levels(total["img_map"], ctx.img_like)
+            levels = total["img_levels"] if like is not None else hip.img_map_grad_to_levels(total["img_map"], ctx.img_like)
             grads += [g if n else None for g, n in zip(levels, needs[i_img:i_vox])]
         else:
             grads += [None] * n_img

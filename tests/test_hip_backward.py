@@ -47,7 +47,9 @@ def hip_gradients(hip, c, grad_sdf, precision, sort_points=True, want=None, map_
     packed_b = hip.prep_mlp_weights_bwd(params, vox.channels, img.channels, precision)
     sdf, ctx = hip.sdf_query(dev(c["query"]), dev(c["trans_mat"]), img, vox, packed, precision=precision,
                              save_for_backward=True, sort_points=sort_points)
-    out = hip.sdf_query_backward(ctx, dev(grad_sdf), packed_b, **(want or {}))
+    want = dict(want or {})
+    in_call = want.pop("levels_in_call", False)
+    out = hip.sdf_query_backward(ctx, dev(grad_sdf), packed_b, img_levels_like=img_in if in_call else None, **want)
     got = {}
     if "trans_mat" in out:
         got["d_trans_mat"] = out["trans_mat"]
@@ -55,7 +57,10 @@ def hip_gradients(hip, c, grad_sdf, precision, sort_points=True, want=None, map_
         got.update({"d_" + k: v for k, v in out["mlp"].items()})
     if "vox" in out:
         got.update({f"d_vox{i}": v.permute(0, 4, 1, 2, 3) for i, v in enumerate(out["vox"])})
-    if "img_map" in out:
+    if "img_levels" in out:
+        got.update({f"d_img{i}": v for i, v in enumerate(out["img_levels"])})
+        got["img_map"] = out["img_map"]
+    elif "img_map" in out:
         got.update({f"d_img{i}": v for i, v in enumerate(hip.img_map_grad_to_levels(out["img_map"], img_in))})
         got["img_map"] = out["img_map"]
     torch.cuda.synchronize()
@@ -276,6 +281,34 @@ def test_zero_upstream_gradient_gives_exact_zeros(hip, precision):
 
 
 # ------------------------------------------------------------------------------------------ errors
+@pytest.mark.gpu
+@pytest.mark.parametrize("overlap", [True, False])
+def test_adjoint_resize_inside_the_call_equals_the_separate_call(hip, golden_dir, overlap):
+    """ListQueryGradArgs.grad_img_levels: the same kernel on the same map gradient, only issued inside
+    list_sdf_query_bwd (beside the scatters still in flight) -> identical bits; the other outputs unchanged."""
+    name = "gsmall"
+    g = np.load(os.path.join(golden_dir, f"hotpath_grad_{name}.npz"))
+    c = cases.build_case(name)
+    _, a = hip_gradients(hip, c, g["grad_sdf"], "bf16x3", want=dict(overlap=overlap))
+    _, b = hip_gradients(hip, c, g["grad_sdf"], "bf16x3", want=dict(overlap=overlap, levels_in_call=True))
+    assert set(a) == set(b)
+    for i in range(5):
+        from_map = hip.img_map_grad_to_levels(dev(b["img_map"]), [dev(m) for m in c["img_maps"]])[i].cpu().numpy()
+        np.testing.assert_array_equal(b[f"d_img{i}"], from_map)
+    for k in a:
+        assert rel_max(b[k], a[k]) < 1e-5, k
+    # the level gradients need the map gradient as their intermediate
+    with pytest.raises(RuntimeError, match="channel counts"):
+        img_in = [dev(m) for m in c["img_maps"]]
+        img = hip.prep_img_maps(img_in, 137, dtype="f32")
+        vox = hip.prep_vox_maps([dev(m) for m in c["vox_maps"]], dtype="f32")
+        params = {k: dev(v) for k, v in c["weights"].items()}
+        packed = hip.prep_mlp_weights(params, vox.channels, img.channels, "bf16x3")
+        packed_b = hip.prep_mlp_weights_bwd(params, vox.channels, img.channels, "bf16x3")
+        sdf, ctx = hip.sdf_query(dev(c["query"]), dev(c["trans_mat"]), img, vox, packed, save_for_backward=True)
+        hip.sdf_query_backward(ctx, torch.zeros_like(sdf), packed_b, img_levels_like=img_in[:4] + [img_in[4][:, :8]])
+
+
 def test_backward_rejects_unsupported_calls(hip):
     c = cases.build_case("gtiny")
     md = "f32"

@@ -37,10 +37,12 @@ for it in range(steps + 2):
     sdf, ctx = hip.sdf_query(inp["query"], inp["trans_mat"], img, vox, packed, precision=precision,
                              save_for_backward=True)
     ev.record(e[2])
+    in_call = os.environ.get("LIST_BWD_LEVELS_IN_CALL", "1") == "1"
     out = hip.sdf_query_backward(ctx, gsdf, packed_b, stage_events=arr,
-                                 overlap=os.environ.get("LIST_BWD_OVERLAP", "1") == "1")
+                                 overlap=os.environ.get("LIST_BWD_OVERLAP", "1") == "1",
+                                 img_levels_like=inp["img_maps"] if in_call else None)
     ev.record(e[3])
-    lv = hip.img_map_grad_to_levels(out["img_map"], inp["img_maps"])
+    lv = out["img_levels"] if in_call else hip.img_map_grad_to_levels(out["img_map"], inp["img_maps"])
     e4 = ev.create(); ev.record(e4)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
