@@ -244,32 +244,45 @@ def run_whole_model(workload, precision, device, steps=5, warmup=2):
     inside the model is visible.  Random-init weights (seed 333), images U[0,1)."""
     from list_amd import arguments, utils
     B, N, img_res, vox_res, _, _ = WORKLOADS[workload]
-    torch.manual_seed(333)
-    cfg = arguments.default_config(vox_res=vox_res, train_batch_size=B, precision=precision, img_res=img_res)
-    net = utils.get_class("network.models.LIST")(cfg).to(device).eval()
     g = torch.Generator(device=device)
     g.manual_seed(333)
     img = torch.rand((B, 3, img_res, img_res), generator=g, device=device)
     query = torch.rand((B, N, 3), generator=g, device=device) - 0.5
-    times = {"encode": 0.0, "query": 0.0}
-    with torch.no_grad():
-        for it in range(warmup + steps):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            feat_l2, vox_feat, tm, _, _ = net.encode(img)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            sdf = net.query_sdf(query, feat_l2, vox_feat, tm)
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            if it >= warmup:
-                times["encode"] += t1 - t0
-                times["query"] += t2 - t1
-    total = (times["encode"] + times["query"]) / steps
-    return {"model": "network.models.LIST (random init, eval)", "precision": precision,
-            "ms_per_forward": total * 1e3, "value": B * N / total, "unit": "query-points/s (whole LIST.forward)",
-            "encode_ms": times["encode"] / steps * 1e3, "query_sdf_ms": times["query"] / steps * 1e3,
-            "channels_last_encoders": bool(net.channels_last), "finite": bool(torch.isfinite(sdf).all())}
+
+    def one(vox_encoder_precision, state=None):
+        torch.manual_seed(333)
+        cfg = arguments.default_config(vox_res=vox_res, train_batch_size=B, precision=precision, img_res=img_res,
+                                       vox_encoder_precision=vox_encoder_precision)
+        net = utils.get_class("network.models.LIST")(cfg).to(device).eval()
+        if state is not None:
+            net.load_state_dict(state)
+        times = {"encode": 0.0, "query": 0.0}
+        with torch.no_grad():
+            for it in range(warmup + steps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                feat_l2, vox_feat, tm, _, _ = net.encode(img)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                sdf = net.query_sdf(query, feat_l2, vox_feat, tm)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                if it >= warmup:
+                    times["encode"] += t1 - t0
+                    times["query"] += t2 - t1
+        total = (times["encode"] + times["query"]) / steps
+        return net, sdf, {"ms_per_forward": total * 1e3, "value": B * N / total,
+                          "encode_ms": times["encode"] / steps * 1e3, "query_sdf_ms": times["query"] / steps * 1e3,
+                          "finite": bool(torch.isfinite(sdf).all())}
+
+    net, sdf, r = one("fp32")
+    out = {"model": "network.models.LIST (random init, eval)", "precision": precision,
+           "unit": "query-points/s (whole LIST.forward)", "channels_last_encoders": bool(net.channels_last), **r}
+    # SURVEY 8 f2, "optionally half precision": the 3-D encoder under autocast hands fp16 channels-last levels over
+    _, sdf_h, rh = one("fp16", net.state_dict())
+    rh["max_abs_sdf_diff_vs_fp32_encoder"] = float((sdf_h - sdf).abs().max())
+    out["vox_encoder_fp16"] = rh
+    return out
 
 
 def roofline_of(kernel_ms, table, precision):

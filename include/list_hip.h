@@ -66,10 +66,13 @@ typedef struct ListMap2D {
   int64_t sb, sc, sh, sw;
 } ListMap2D;
 
-/* One 3-D feature map [B,C,D,H,W] float32 with element strides. */
+/* One 3-D feature map [B,C,D,H,W] with element strides.  dtype (enum ListMapDtype): LIST_MAP_F32, or
+ * LIST_MAP_F16 for a producer that runs in half precision (a channels-last fp16 level with
+ * C % 8 == 0 is then used where it lies when fp16 maps are asked for; anything else is converted). */
 typedef struct ListMap3D {
-  const float* data;
+  const void* data;
   int32_t C, D, H, W;
+  int32_t dtype, reserved_;
   int64_t sb, sc, sd, sh, sw;
 } ListMap3D;
 

@@ -77,6 +77,10 @@ def build_parser():
     # --- MI355X path
     p.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp16", "bf16"],
                    help="arithmetic of the implicit MLP on the HIP path")
+    p.add_argument("--vox_encoder_precision", default="fp32", choices=["fp32", "fp16"],
+                   help="fp16: the 3-D encoder runs under autocast (MIOpen half kernels, 2.5x faster at 128^3) and "
+                        "hands fp16 channels-last levels to the query path, which uses them where they lie; "
+                        "changes the features by ~3e-4, so it is opt-in and meant for --precision fp16")
     p.add_argument("--channels_last", type=_bool, default=True,
                    help="run the encoders that feed the query path in channels-last memory format")
     p.add_argument("--synthetic_len", type=int, default=64, help="items per epoch of the synthetic datasets")

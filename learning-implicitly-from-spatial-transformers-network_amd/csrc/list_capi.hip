@@ -28,9 +28,18 @@ constexpr int64_t kMaxChunkRows = 262144;     // bounds the workspace (~4.6 GB) 
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-bool vox_in_place(const ListMap3D& m, ListVoxLevel* lv) {
+bool vox_in_place(const ListMap3D& m, ListVoxLevel* lv, int32_t map_dtype) {
   const int64_t C = m.C, W = m.W, H = m.H;
   lv->C = m.C; lv->D = m.D; lv->H = m.H; lv->W = m.W; lv->dtype = LIST_MAP_F32; lv->reserved_ = 0;
+  if (m.dtype == LIST_MAP_F16) {
+    // a half-precision producer: its channels-last levels are the fp16 maps themselves; scalar levels and
+    // requests for fp32 maps go through the converting copy
+    if (map_dtype != LIST_MAP_F16 || m.C == 1 || (m.C % 8) != 0) return false;
+    if (m.sc == 1 && m.sw == C && m.sh == W * C && m.sd == H * W * C && aligned16(m.data) && (m.sb % 8) == 0) {
+      lv->data = m.data; lv->image_stride = m.sb; lv->dtype = LIST_MAP_F16; return true;
+    }
+    return false;
+  }
   if (m.C == 1) {
     if (m.sw == 1 && m.sh == W && m.sd == H * W) { lv->data = m.data; lv->image_stride = m.sb; return true; }
     return false;
@@ -161,7 +170,8 @@ size_t list_vox_pack_bytes(const ListMap3D maps[LIST_N_VOX_LEVELS], int32_t B, i
   size_t total = 0;
   for (int l = 0; l < LIST_N_VOX_LEVELS; ++l) {
     ListVoxLevel lv;
-    if (vox_in_place(maps[l], &lv)) continue;
+    if (!dtype_ok(maps[l].dtype)) return 0;
+    if (vox_in_place(maps[l], &lv, map_dtype)) continue;
     total += align_up((size_t)B * maps[l].C * maps[l].D * maps[l].H * maps[l].W *
                       (level_as_f16(maps[l], map_dtype) ? 2 : 4), 256);
   }
@@ -174,6 +184,8 @@ int list_prep_vox_maps(const ListMap3D maps[LIST_N_VOX_LEVELS], int32_t B, int32
   if (!maps || !levels_out) return fail(LIST_ERR_ARG, "maps/levels_out is NULL");
   if (!dtype_ok(map_dtype)) return fail(LIST_ERR_ARG, "map_dtype=%d", map_dtype);
   if (B <= 0 || B > 65535) return fail(LIST_ERR_SHAPE, "B=%d", B);
+  for (int l = 0; l < LIST_N_VOX_LEVELS; ++l)
+    if (!dtype_ok(maps[l].dtype)) return fail(LIST_ERR_ARG, "voxel level %d: dtype=%d", l, maps[l].dtype);
   const size_t need = list_vox_pack_bytes(maps, B, map_dtype);
   if (need > 0 && (!pack || pack_bytes < need))
     return fail(LIST_ERR_WORKSPACE, "pack buffer too small: %zu < %zu", pack_bytes, need);
@@ -185,7 +197,7 @@ int list_prep_vox_maps(const ListMap3D maps[LIST_N_VOX_LEVELS], int32_t B, int32
       return fail(LIST_ERR_SHAPE, "voxel level %d: bad descriptor", l);
     if ((int64_t)m.D * m.H * m.W * m.C >= (int64_t)1 << 31)
       return fail(LIST_ERR_SHAPE, "voxel level %d: image larger than 2^31 elements", l);
-    if (vox_in_place(m, &levels_out[l])) continue;
+    if (vox_in_place(m, &levels_out[l], map_dtype)) continue;
     const bool f16 = level_as_f16(m, map_dtype);
     void* dst = (char*)pack + off;
     hipError_t e = launch_transpose_vox(m, B, f16, dst, (hipStream_t)stream);

@@ -276,9 +276,14 @@ __global__ __launch_bounds__(256) void k_transpose_vox(ListMap3D m, int c_begin,
     const int hw = m.H * m.W;
     const int z = v / hw, r = v - z * hw;
     const int y = r / m.W, x = r - y * m.W;
-    const float* src = m.data + (int64_t)b * m.sb + (int64_t)z * m.sd + (int64_t)y * m.sh
-                       + (int64_t)x * m.sw;
-    for (int c = wave; c < nc; c += 4) tile[c * 65 + lane] = src[(int64_t)(c_begin + c) * m.sc];
+    const int64_t at = (int64_t)b * m.sb + (int64_t)z * m.sd + (int64_t)y * m.sh + (int64_t)x * m.sw;
+    if (m.dtype == LIST_MAP_F16) {
+      const _Float16* src = (const _Float16*)m.data + at;
+      for (int c = wave; c < nc; c += 4) tile[c * 65 + lane] = (float)src[(int64_t)(c_begin + c) * m.sc];
+    } else {
+      const float* src = (const float*)m.data + at;
+      for (int c = wave; c < nc; c += 4) tile[c * 65 + lane] = src[(int64_t)(c_begin + c) * m.sc];
+    }
   }
   __syncthreads();
   const int nv = min(64, nvox - v0);
@@ -353,9 +358,9 @@ static hipError_t launch_transpose_tile(const ListMap3D& m, int B, int f16, void
   const int nvox = m.D * m.H * m.W;
   const dim3 grid(nvox / (8192 / C), B);
   if (f16)
-    hipLaunchKernelGGL((k_transpose_vox_tile<C, 1>), grid, dim3(256), 0, s, m.data, m.sb, m.sc, nvox, out);
+    hipLaunchKernelGGL((k_transpose_vox_tile<C, 1>), grid, dim3(256), 0, s, (const float*)m.data, m.sb, m.sc, nvox, out);
   else
-    hipLaunchKernelGGL((k_transpose_vox_tile<C, 0>), grid, dim3(256), 0, s, m.data, m.sb, m.sc, nvox, out);
+    hipLaunchKernelGGL((k_transpose_vox_tile<C, 0>), grid, dim3(256), 0, s, (const float*)m.data, m.sb, m.sc, nvox, out);
   return hipGetLastError();
 }
 
@@ -364,7 +369,7 @@ hipError_t launch_transpose_vox(const ListMap3D& m, int B, int f16, void* out, h
   const bool spatial_contig = m.sw == 1 && m.sh == m.W && m.sd == (int64_t)m.H * m.W;
   const bool aligned = (reinterpret_cast<uintptr_t>(m.data) & 15) == 0 && (m.sb % 4) == 0 &&
                        (m.sc % 4) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
-  if (spatial_contig && aligned && (m.C == 16 || m.C == 32 || m.C == 64 || m.C == 128) &&
+  if (m.dtype == LIST_MAP_F32 && spatial_contig && aligned && (m.C == 16 || m.C == 32 || m.C == 64 || m.C == 128) &&
       nvox % (8192 / m.C) == 0) {
     switch (m.C) {
       case 16: return launch_transpose_tile<16>(m, B, f16, out, s);

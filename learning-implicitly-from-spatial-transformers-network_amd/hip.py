@@ -36,7 +36,8 @@ class ListMap2D(C.Structure):
 
 class ListMap3D(C.Structure):
     _fields_ = [("data", C.c_void_p), ("C", C.c_int32), ("D", C.c_int32), ("H", C.c_int32),
-                ("W", C.c_int32), ("sb", C.c_int64), ("sc", C.c_int64), ("sd", C.c_int64),
+                ("W", C.c_int32), ("dtype", C.c_int32), ("reserved_", C.c_int32),
+                ("sb", C.c_int64), ("sc", C.c_int64), ("sd", C.c_int64),
                 ("sh", C.c_int64), ("sw", C.c_int64)]
 
 
@@ -239,7 +240,8 @@ def prep_img_maps(img_featuremaps, map_size=137, dtype="f32"):
 
 
 def prep_vox_maps(vox_feat, dtype="f32"):
-    """Layout hand-off for the 3-D grid_sample of network/modules.py:263-265."""
+    """Layout hand-off for the 3-D grid_sample of network/modules.py:263-265.  Levels may be float32 or, from a
+    half-precision producer, float16 (channels-last fp16 levels are used where they lie when dtype is 'f16')."""
     lib = load()
     md = MAP_DTYPES[dtype]
     if len(vox_feat) != N_VOX_LEVELS:
@@ -247,10 +249,12 @@ def prep_vox_maps(vox_feat, dtype="f32"):
     maps = (ListMap3D * N_VOX_LEVELS)()
     B = vox_feat[0].shape[0]
     for i, t in enumerate(vox_feat):
-        _f32_cuda(t, f"vox_feat[{i}]")
+        if not (torch.is_tensor(t) and t.is_cuda and t.dtype in (torch.float32, torch.float16)):
+            raise RuntimeError(f"vox_feat[{i}] must be a float32 or float16 CUDA tensor")
         if t.dim() != 5 or t.shape[0] != B:
             raise RuntimeError(f"vox_feat[{i}] must be [B,C,D,H,W]")
-        maps[i] = ListMap3D(t.data_ptr(), t.shape[1], t.shape[2], t.shape[3], t.shape[4], *t.stride())
+        maps[i] = ListMap3D(t.data_ptr(), t.shape[1], t.shape[2], t.shape[3], t.shape[4],
+                            MAP_F16 if t.dtype == torch.float16 else MAP_F32, 0, *t.stride())
     need = lib.list_vox_pack_bytes(maps, B, md)
     dev = vox_feat[0].device
     pack = torch.empty((max(need, 16) // 4,), dtype=torch.float32, device=dev)

@@ -88,6 +88,7 @@ class _SdfQueryHipFn(torch.autograd.Function):
             ctx.pieces.append((n0, n1, qctx))
         ctx.img_like = [t.detach() for t in tensors[:ctx.n_img]]      # shapes/strides of the encoder maps
         ctx.mlp_shapes = [t.shape for t in tensors[ctx.n_img + N_VOX:]]
+        ctx.vox_dtypes = [t.dtype for t in tensors[ctx.n_img:ctx.n_img + N_VOX]]
         return parts[0] if len(parts) == 1 else torch.cat(parts, 1)
 
     @staticmethod
@@ -134,7 +135,8 @@ class _SdfQueryHipFn(torch.autograd.Function):
         else:
             grads += [None] * n_img
         if want_vox:       # channels-last buffers seen as [B,C,D,H,W]
-            grads += [g.permute(0, 4, 1, 2, 3) if n else None for g, n in zip(total["vox"], needs[i_vox:i_mlp])]
+            grads += [g.permute(0, 4, 1, 2, 3).to(dt) if n else None
+                      for g, n, dt in zip(total["vox"], needs[i_vox:i_mlp], ctx.vox_dtypes)]
         else:
             grads += [None] * N_VOX
         if want_mlp:
@@ -187,7 +189,8 @@ def sdf_query(query, trans_mat, img_maps, vox_maps, mlp_params, *, perm=(2, 1, 0
     require_hip(query, "query")
     caches = caches or {}
     query = _f32(query)
-    vox_maps = [_f32(v) for v in vox_maps]
+    # a half-precision producer's vector levels stay fp16 (used where they lie); its scalar level is read as fp32
+    vox_maps = [v if (v.dtype == torch.float16 and v.shape[1] > 1) else _f32(v) for v in vox_maps]
     mlp = [mlp_params[k] for k in MLP_KEYS]
     md = hip.map_dtype_for(precision)
     if percep_feat is None:

@@ -32,6 +32,7 @@ class LIST(nn.Module):
         # channels-last, so their outputs already have the [..spatial..][C] layout the gathers read and
         # list_prep_vox_maps is a no-op (MIOpen NDHWC/NHWC convolutions: same results, same speed).
         self.channels_last = bool(getattr(config, "channels_last", True))
+        self.vox_encoder_half = getattr(config, "vox_encoder_precision", "fp32") == "fp16"
         self.vox_encoder = M.VoxelEncoder2(config.im_enc_layers)
         self.sdf_decoder = M.VoxelDecoder2(enc_feat_size, 256)
         self.sdf_decoder.precision = getattr(config, "precision", "bf16x3")
@@ -66,7 +67,11 @@ class LIST(nn.Module):
             code = torch.cat([coarse, feat_g2.reshape(img.shape[0], -1)], dim=1)
             trans_mat = self.spatial_transformer(code).reshape(-1, 4, 3)
         occ = self.create_occ(pc)
-        vox_feat = self.vox_encoder(occ)
+        if self.vox_encoder_half and occ.is_cuda:
+            with torch.autocast("cuda", dtype=torch.float16):
+                vox_feat = self.vox_encoder(occ)
+        else:
+            vox_feat = self.vox_encoder(occ)
         if use_cl:      # MIOpen keeps the format; levels that lost it would simply be transposed again
             vox_feat = [v if v.shape[1] == 1 else v.contiguous(memory_format=torch.channels_last_3d)
                         for v in vox_feat]
@@ -80,7 +85,7 @@ class LIST(nn.Module):
     def forward(self, img, query, trans_mat=None):
         feat_l2, vox_feat, trans_mat, _, _ = self.encode(img, trans_mat)
         sdf = self.query_sdf(query, feat_l2, vox_feat, trans_mat)
-        return vox_feat[0], sdf
+        return vox_feat[0].float(), sdf                     # (a no-op unless the 3-D encoder ran in half precision)
 
     def create_occ(self, pc):
         """Voxelise the coarse cloud: nearest node of the regular bb grid gets 1.  The reference asks

@@ -360,6 +360,32 @@ def test_autograd_function_routes_through_the_hip_backward(hip, golden_dir, monk
     assert rel_max(T2.grad.cpu().numpy(), g["d_trans_mat"]) < TOL_X3_RELMAX
 
 
+def test_half_precision_voxel_leaves_get_half_gradients(hip):
+    """A half-precision 3-D encoder: fp16 channels-last voxel leaves are used where they lie; their
+    gradients come back in fp16 and equal the fp32 leaves' gradients (same values in the maps) after rounding."""
+    from list_amd.network import hotpath
+    c = cases.build_case("gtiny")
+    gsdf = torch.randn((c["query"].shape[0], c["query"].shape[1]), device="cuda:0")
+    W = {k: dev(v) for k, v in c["weights"].items()}
+    img = [dev(m) for m in c["img_maps"]]
+    grads = {}
+    for kind in ("half", "float"):
+        vox = []
+        for m in c["vox_maps"]:
+            t = dev(m).half()
+            t = t.contiguous(memory_format=torch.channels_last_3d) if kind == "half" else t.float()
+            vox.append(t.requires_grad_(True))
+        sdf = hotpath.sdf_query(dev(c["query"]), dev(c["trans_mat"]), img, vox, W, precision="fp16")
+        (sdf * gsdf).sum().backward()
+        grads[kind] = [t.grad for t in vox]
+        grads[kind + "_sdf"] = sdf.detach()
+    assert torch.equal(grads["half_sdf"], grads["float_sdf"])
+    for h, f in zip(grads["half"], grads["float"]):
+        assert h.dtype == torch.float16 and f.dtype == torch.float32 and h.shape == f.shape
+        scale = float(f.abs().max()) + 1e-30
+        assert float((h.float() - f).abs().max()) <= 2e-3 * scale          # fp16 rounding of the same sums (+ atomics order)
+
+
 def _leaves(c):
     leaf = lambda a: dev(a).requires_grad_(True)
     return ([leaf(m) for m in c["img_maps"]], [leaf(m) for m in c["vox_maps"]], leaf(c["trans_mat"]),

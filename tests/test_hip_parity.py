@@ -160,6 +160,38 @@ def test_prep_vox_accepts_channels_last_in_place(hip):
     np.testing.assert_array_equal(sdf_cl, sdf)
 
 
+@pytest.mark.parametrize("precision", ["fp16", "bf16x3"])
+def test_half_precision_voxel_levels_are_used_where_they_lie(hip, precision):
+    """SURVEY 8 f2 ('optionally half precision'): fp16 levels from an autocast producer.  Channels-last fp16
+    levels are zero-copy when fp16 maps are asked for; every other combination goes through the converting
+    copy.  Against fp32 levels holding the same (fp16-representable) values the SDF is identical bit for bit."""
+    c = cases.build_case("small")
+    md = hip.map_dtype_for(precision)
+    maps32 = [dev(m).half().float() for m in c["vox_maps"]]
+    half_cl = [m.half().contiguous(memory_format=torch.channels_last_3d) for m in maps32]
+    half_nc = [m.half().contiguous() for m in maps32]
+    img = hip.prep_img_maps([dev(m) for m in c["img_maps"]], dtype=md)
+    ref_vox = hip.prep_vox_maps(maps32, dtype=md)
+    packed = hip.prep_mlp_weights({k: dev(v) for k, v in c["weights"].items()}, ref_vox.channels, img.channels,
+                                  precision)
+    q, tm = dev(c["query"]), dev(c["trans_mat"])
+    ref = hip.sdf_query(q, tm, img, ref_vox, packed, precision=precision).cpu().numpy()
+    for maps, in_place in ((half_cl, md == "f16"), (half_nc, False)):
+        vox = hip.prep_vox_maps(maps, dtype=md)
+        for l, t in enumerate(maps):
+            if t.shape[1] == 1:
+                assert vox.levels[l].dtype == hip.MAP_F32                       # scalar levels are converted
+            elif in_place:
+                assert vox.levels[l].data == t.data_ptr() and vox.levels[l].dtype == hip.MAP_F16
+            else:
+                assert vox.levels[l].data != t.data_ptr()
+                assert vox.levels[l].dtype == (hip.MAP_F16 if md == "f16" else hip.MAP_F32)
+        got = hip.sdf_query(q, tm, img, vox, packed, precision=precision).cpu().numpy()
+        np.testing.assert_array_equal(got, ref)
+    with pytest.raises(RuntimeError, match="float32 or float16"):
+        hip.prep_vox_maps([m.double() for m in maps32])
+
+
 def test_prep_img_channels_last_source_is_bit_identical(hip):
     c = cases.build_case("small")
     nchw = [dev(m) for m in c["img_maps"]]

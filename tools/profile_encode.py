@@ -45,3 +45,21 @@ with torch.no_grad():
     print(f"point_mlp_coarse              {t:8.3f} ms")
     t, _ = timed(lambda: net.encode(img))
     print(f"encode() total                {t:8.3f} ms")
+    # library knobs for the 3-D encoder (out of the hot path's scope; measured for the hand-off row only)
+    for name, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+        def run(dt=dt):
+            with torch.autocast("cuda", dtype=dt):
+                return net.vox_encoder(occ)
+        t, v16 = timed(run)
+        err = max(float((a.float() - b).abs().max()) for a, b in zip(v16, vox))
+        print(f"vox_encoder autocast {name}     {t:8.3f} ms   max|diff| vs fp32 {err:.3e}  formats "
+              f"{[('cl' if a.is_contiguous(memory_format=torch.channels_last_3d) else 'nc') for a in v16]}")
+    net2 = utils.get_class("network.models.LIST")(cfg).to(dev).eval()          # plain NCDHW encoder
+    net2.vox_encoder.load_state_dict(net.vox_encoder.state_dict())
+    t, _ = timed(lambda: net2.vox_encoder(occ))
+    print(f"vox_encoder NCDHW fp32        {t:8.3f} ms")
+    torch.backends.cudnn.benchmark = True
+    t, _ = timed(lambda: net2.vox_encoder(occ), n=5)
+    print(f"vox_encoder NCDHW fp32 + benchmark(find) {t:8.3f} ms")
+    t, _ = timed(lambda: net.vox_encoder(occ), n=5)
+    print(f"vox_encoder NDHWC fp32 + benchmark(find) {t:8.3f} ms")
