@@ -79,10 +79,14 @@ __device__ __forceinline__ void stage_tiles(const GemmParams& p, char* sbase, in
     const int64_t aoff = (int64_t)(m0 + row) * ld + kbyte + chunk * 16;
     const int64_t woff = (int64_t)(n0 + row) * ld + kbyte + chunk * 16;
     char* l = sbase + piece * 1024;
+#ifndef LIST_GEMM_NO_A
     glds16(p.a_hi + aoff, l);
     if (TERMS == 3) glds16(p.a_lo + aoff, l + P::kPlaneBytes);
+#endif
+#ifndef LIST_GEMM_NO_W
     glds16(p.w_hi + woff, l + P::kWOff);
     if (TERMS == 3) glds16(p.w_lo + woff, l + P::kWOff + P::kPlaneBytes);
+#endif
   }
 }
 
