@@ -87,6 +87,37 @@ def test_encoders_emit_channels_last_maps_used_in_place(net):
     net.cpu()
 
 
+def test_half_precision_voxel_encoder_hands_its_levels_over_in_place(cfg, net):
+    """SURVEY 8 f2 ('optionally half precision'): --vox_encoder_precision fp16 runs the 3-D encoder under autocast;
+    its fp16 channels-last levels are the fp16 maps of the query path (no copy), the SDF stays close to the fp32
+    encoder's and a training step differentiates through it (fp16 voxel gradients into the encoder)."""
+    from list_amd import hip
+    cfg_h = arguments.default_config(vox_res=32, train_batch_size=2, precision="fp16", vox_encoder_precision="fp16")
+    cfg_f = arguments.default_config(vox_res=32, train_batch_size=2, precision="fp16")
+    half = utils.get_class("network.models.LIST")(cfg_h)
+    full = utils.get_class("network.models.LIST")(cfg_f)
+    half.load_state_dict(net.state_dict()), full.load_state_dict(net.state_dict())
+    half.to(DEV).eval(), full.to(DEV).eval()
+    img = torch.from_numpy(synth.uniform(78, (2, 3, 64, 64))).to(DEV)
+    q = torch.from_numpy(synth.make_query(5, 2, 200)).to(DEV)
+    with torch.no_grad():
+        feat_l2, vox_feat, tm, _, _ = half.encode(img)
+        assert all(v.dtype == torch.float16 for v in vox_feat)
+        vox = hip.prep_vox_maps(vox_feat, "f16")
+        for l, v in enumerate(vox_feat):
+            if v.shape[1] > 1 and v.shape[2] > 1:
+                assert vox.levels[l].data == v.data_ptr() and vox.levels[l].dtype == hip.MAP_F16
+        occ_h, sdf_h = half(img, q)
+        occ_f, sdf_f = full(img, q)
+    assert occ_h.dtype == torch.float32 and torch.isfinite(sdf_h).all()
+    assert float((sdf_h - sdf_f).abs().max()) < 5e-3 * max(1.0, float(sdf_f.abs().max()))
+    half.train()
+    occ, sdf = half(img, q)
+    (sdf.square().mean() + occ.mean()).backward()
+    g = half.vox_encoder.conv["conv_3"].weight.grad
+    assert g is not None and g.dtype == torch.float32 and torch.isfinite(g).all() and float(g.abs().sum()) > 0
+
+
 def test_prepared_map_cache_is_not_fooled_by_address_reuse(net):
     """Fresh encoder outputs usually land on the addresses of the freed previous ones (same shapes,
     version 0): the prepared-map cache must key on tensor identity, not on data_ptr."""
