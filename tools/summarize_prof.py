@@ -53,8 +53,8 @@ def main():
                 r = v[-1][1]
                 out.append(f"{k:34s} {len(ts):6d} {sum(ts)/len(ts)/1e3:10.1f} {min(ts)/1e3:10.1f} "
                            f"{max(ts)/1e3:10.1f} {sum(ts)/1e6:10.3f} {r.get('VGPR_Count',''):>5s} "
-                           f"{r.get('LDS_Block_Size',''):>7s} {r.get('Grid_Size',''):>9s} "
-                           f"{r.get('Workgroup_Size',''):>5s}")
+                           f"{r.get('LDS_Block_Size',''):>7s} {r.get('Grid_Size_X', r.get('Grid_Size','')):>9s} "
+                           f"{r.get('Workgroup_Size_X', r.get('Workgroup_Size','')):>5s}")
         cs = counters(d)
         if cs:
             out.append(f"== counters: {d}  (per-dispatch mean; FETCH_SIZE/WRITE_SIZE in KB as reported)")
