@@ -252,6 +252,30 @@ def compare_with_oracle(hip, c, map_size=137, **kw):
         assert rel_max(got[k], r.numpy()) < TOL_X3_RELMAX, (k, rel_max(got[k], r.numpy()))
 
 
+def test_another_architecture_forward_and_backward(hip):
+    """The ABI is not tied to the default widths: six voxel levels of 1/8/16/32/64/256 channels (im_enc_layers =
+    [.., 8, 16, 32, 64, 256]) and a narrower 2-D pyramid (32/32/64/128/256 = 512 channels): F = 377*7 + 512 + 3 = 3154."""
+    vox_c, img_c = (1, 8, 16, 32, 64, 256), (32, 32, 64, 128, 256)
+
+    def make(seed):
+        B, n, vox_res, img_res = 2, 77, 32, 64
+        res = [vox_res, vox_res, vox_res // 2, vox_res // 4, vox_res // 8, vox_res // 16]
+        vox = [synth.uniform(seed + 1000, (B, 1, res[0], res[0], res[0]))]
+        vox += [synth.normalish(seed + 1000 + 13 * i, (B, c, r, r, r)) for i, (c, r) in enumerate(zip(vox_c[1:], res[1:]), 1)]
+        img = [synth.normalish(seed + 11 * i, (B, c, max(img_res >> i, 1), max(img_res >> i, 1))) for i, c in enumerate(img_c)]
+        F = sum(vox_c) * 7 + sum(img_c) + 3
+        w = synth.make_mlp_weights(seed, feature_size=F, h_dim=256)
+        return {"query": synth.make_query(seed, B, n), "img_maps": img, "vox_maps": vox,
+                "trans_mat": synth.make_trans_mat(seed, B), "weights": w}
+    c = margin_case(make, range(700, 760))
+    assert c["weights"]["fc_0.weight"].shape[1] == 3154
+    ref_sdf, _ = TO.list_query_grads(*TO.to_torch(c), torch.zeros(c["query"].shape[:2]))
+    sdf, _ = hip_gradients(hip, c, np.zeros(c["query"].shape[:2], np.float32), "bf16x3")
+    assert float((sdf.cpu() - ref_sdf).abs().max()) < 1e-4
+    compare_with_oracle(hip, c)
+    compare_with_oracle(hip, c, want=dict(vox_adjoint="scatter"))
+
+
 def test_backward_with_a_map_wider_than_the_pixel_sort(hip):
     """map_size = 190 (like config 5's 274): the forward builds no pixel order, so the perceptual-map
     gradient takes the atomic form and trans_mat / the resize adjoint run at another size."""
