@@ -133,11 +133,21 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
         pre = [ev.create() for _ in range(4)]
         arr = (ctypes.c_void_p * n_ev)(*[ev.create() for _ in range(n_ev)])
         step_events.append((pre, arr))
-    gathered = torch.empty((world * B, N), dtype=torch.float32, device=device) if world > 1 else None
-    sdf = torch.empty((B, N), dtype=torch.float32, device=device)
+    # N > 1: the exchange of step i (one RCCL all-gather of the SDF shards) runs on RCCL's stream beside the kernels
+    # of step i+1; two output buffers alternate, and a step first orders itself after the gather that last read its buffer
+    gathered = [torch.empty((world * B, N), dtype=torch.float32, device=device) for _ in range(2)] if world > 1 else None
+    sdfs = [torch.empty((B, N), dtype=torch.float32, device=device) for _ in range(2 if world > 1 else 1)]
+    pending = [None, None]
+    n_calls = [0]
 
     def step(events=None):
         pre, arr = events if events else (None, None)
+        k = n_calls[0] % len(sdfs)
+        n_calls[0] += 1
+        sdf = sdfs[k]
+        if pending[k] is not None:
+            pending[k].wait()
+            pending[k] = None
         if pre: ev.record(pre[0])
         md = hip.map_dtype_for(precision)
         img = hip.prep_img_maps(inp["img_maps"], inp["map_size"], md)
@@ -149,11 +159,18 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
         hip.sdf_query(inp["query"], inp["trans_mat"], img, vox, packed, precision=precision,
                       out=sdf, stage_events=arr, clamp_hi=inp["clamp_hi"])
         if world > 1:
-            gather_fn(sdf, out=gathered)
+            _, pending[k] = gather_fn(sdf, out=gathered[k], async_op=True)
         return sdf
+
+    def drain():
+        for k in range(2):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
 
     for _ in range(warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -161,6 +178,7 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
     t0 = time.perf_counter()
     for i in range(steps):
         step(step_events[i])
+    drain()                                   # every exchange has completed inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -180,7 +198,7 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
         for s in range(n_ev - 1):
             acc[3 + s] += ev.elapsed_ms(ctypes.c_void_p(arr[s]), ctypes.c_void_p(arr[s + 1]))
     kernel_ms = dict(zip(names, (acc / steps).tolist()))
-    return elapsed, kernel_ms, sdf
+    return elapsed, kernel_ms, sdfs[(n_calls[0] - 1) % len(sdfs)]
 
 
 def run_train_step(precision, steps, warmup, inp, hip, ev):

@@ -28,14 +28,20 @@ def shard_range(total, rank, world):
     return begin, begin + base + (1 if rank < extra else 0)
 
 
-def gather_sdf_shards(sdf_local, out=None, group=None):
-    """All-gather equally-shaped SDF shards along dim 0 -> [world*B_local, N]."""
+def gather_sdf_shards(sdf_local, out=None, group=None, async_op=False):
+    """All-gather equally-shaped SDF shards along dim 0 -> [world*B_local, N].
+
+    async_op=True (RCCL only) returns (out, work): the collective runs on RCCL's stream behind the work already
+    queued on the current stream, and the caller's next kernels do not wait for it; `work.wait()` orders the
+    current stream after it (needed before `out` is read or `sdf_local` is overwritten).  Other backends and a
+    single process complete in place and return (out, None)."""
     rank, world = world_info(group)
     if world == 1:
         if out is None:
-            return sdf_local
-        out.copy_(sdf_local)
-        return out
+            out = sdf_local
+        else:
+            out.copy_(sdf_local)
+        return (out, None) if async_op else out
     sdf_local = sdf_local.contiguous()
     if out is None:
         out = torch.empty((world * sdf_local.shape[0],) + tuple(sdf_local.shape[1:]),
@@ -45,9 +51,11 @@ def gather_sdf_shards(sdf_local, out=None, group=None):
         host = torch.empty(out.shape, dtype=out.dtype)
         dist.all_gather_into_tensor(host, sdf_local.cpu(), group=group)
         out.copy_(host)
-        return out
+        return (out, None) if async_op else out
+    if async_op and sdf_local.is_cuda:
+        return out, dist.all_gather_into_tensor(out, sdf_local, group=group, async_op=True)
     dist.all_gather_into_tensor(out, sdf_local, group=group)
-    return out
+    return (out, None) if async_op else out
 
 
 def gather_ragged_points(values_local, total, group=None):

@@ -26,6 +26,12 @@ def _worker(rank, world, port, out_dir):
         b, e = P.shard_range(6, rank, world)
         gathered = P.gather_sdf_shards(full_pred[b:e].clone())
         assert torch.equal(gathered, full_pred)                       # bit-for-bit
+        # the overlapped form bench.py uses (a work handle with RCCL, completed in place elsewhere)
+        out = torch.empty_like(full_pred)
+        got, work = P.gather_sdf_shards(full_pred[b:e].clone(), out=out, async_op=True)
+        if work is not None:
+            work.wait()
+        assert got is out and torch.equal(out, full_pred)
         loss = P.full_batch_sdf_loss(full_pred[b:e].clone(), full_tgt[b:e].clone(), 2.0)
         ref = torch.mean(((full_tgt * 2.0 - full_pred) ** 2).sum(-1))
         assert torch.equal(loss, ref)
@@ -61,4 +67,6 @@ def test_single_process_passthrough():
     from list_amd import parallel as P
     x = torch.arange(6.0).reshape(2, 3)
     assert P.gather_sdf_shards(x) is x
+    got, work = P.gather_sdf_shards(x, async_op=True)
+    assert got is x and work is None
     assert P.world_info() == (0, 1)
