@@ -276,6 +276,25 @@ def test_another_architecture_forward_and_backward(hip):
     compare_with_oracle(hip, c, want=dict(vox_adjoint="scatter"))
 
 
+def test_backward_on_odd_shapes(hip):
+    """Non-square odd 2-D levels and non-cubic voxel levels: the adjoint resize, the three voxel adjoint forms' level
+    classification and the image-gradient gather on sizes that fit no fast path."""
+    img_hw = [(50, 46), (25, 23), (13, 12), (7, 6), (4, 3)]
+    vox_dhw = [(12, 20, 28), (12, 20, 28), (6, 10, 14), (3, 5, 7), (2, 3, 4), (1, 2, 2)]
+
+    def make(seed):
+        B, n = 2, 61
+        img = [synth.normalish(seed + i, (B, c, h, w)) for i, (c, (h, w)) in enumerate(zip(synth.IMG_CHANNELS, img_hw))]
+        vox = [synth.uniform(seed + 50, (B, 1) + vox_dhw[0])]
+        vox += [synth.normalish(seed + 50 + i, (B, c) + d) for i, (c, d) in enumerate(zip(synth.VOX_CHANNELS[1:], vox_dhw[1:]), 1)]
+        return {"query": synth.make_query(seed, B, n), "img_maps": img, "vox_maps": vox,
+                "trans_mat": synth.make_trans_mat(seed, B), "weights": synth.make_mlp_weights(seed)}
+    c = margin_case(make, range(800, 860))
+    compare_with_oracle(hip, c)
+    compare_with_oracle(hip, c, want=dict(vox_adjoint="gather"))
+    compare_with_oracle(hip, c, want=dict(overlap=False, levels_in_call=True))
+
+
 def test_backward_with_a_map_wider_than_the_pixel_sort(hip):
     """map_size = 190 (like config 5's 274): the forward builds no pixel order, so the perceptual-map
     gradient takes the atomic form and trans_mat / the resize adjoint run at another size."""

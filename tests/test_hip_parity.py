@@ -244,6 +244,42 @@ def test_percep_pool_matches_reference(hip, golden_dir, name):
     np.testing.assert_allclose(out[:, :, :, ::4], g["percep_sub"], rtol=0, atol=2e-5)
 
 
+def test_odd_shapes_take_the_general_paths(hip):
+    """Levels whose sizes fit none of the fast kernels' preconditions: odd 2-D maps (50, 25, 13, 7, 4 pixels, non-square),
+    non-cubic voxel levels, a strided (sliced) source tensor, N = 1 .. -- the strided fall-back kernels against the
+    numpy oracle, features and SDF."""
+    from oracle import synth
+    B, N = 2, 53
+    img_hw = [(50, 46), (25, 23), (13, 12), (7, 6), (4, 3)]
+    img = [synth.normalish(900 + i, (B, c, h, w)) for i, (c, (h, w)) in enumerate(zip(synth.IMG_CHANNELS, img_hw))]
+    vox_dhw = [(12, 20, 28), (12, 20, 28), (6, 10, 14), (3, 5, 7), (2, 3, 4), (1, 2, 2)]
+    vox = [synth.uniform(950, (B, 1) + vox_dhw[0])]
+    vox += [synth.normalish(950 + i, (B, c) + d) for i, (c, d) in enumerate(zip(synth.VOX_CHANNELS[1:], vox_dhw[1:]), 1)]
+    c = {"query": synth.make_query(77, B, N), "img_maps": img, "vox_maps": vox,
+         "trans_mat": synth.make_trans_mat(77, B), "weights": synth.make_mlp_weights(77)}
+    q = O.permute_scale_query(c["query"])
+    percep = O.perceptual_pooling(img, q, c["trans_mat"]).reshape(B, -1, N)
+    ref_feat = O.concat_features(q, vox, percep)
+    ref_sdf = O.mlp(ref_feat, c["weights"])
+    # sources as slices of larger tensors: batch and channel strides are not the dense ones
+    img_t = [torch.cat([dev(m), dev(m)], 1)[:, :m.shape[1]] for m in img]
+    vox_t = [torch.cat([dev(m), dev(m)], 0)[:B] if m.shape[1] == 1 else torch.cat([dev(m), dev(m)], 1)[:, :m.shape[1]]
+             for m in vox]
+    for md, prec in (("f32", "bf16x3"), ("f16", "fp16")):
+        img_p = hip.prep_img_maps(img_t, dtype=md)
+        vox_p = hip.prep_vox_maps(vox_t, dtype=md)
+        packed = hip.prep_mlp_weights({k: dev(v) for k, v in c["weights"].items()}, vox_p.channels, img_p.channels, prec)
+        feats = hip.gather_features(dev(c["query"]), dev(c["trans_mat"]), img_p, vox_p, packed).cpu().numpy()
+        sdf = hip.sdf_query(dev(c["query"]), dev(c["trans_mat"]), img_p, vox_p, packed, precision=prec).cpu().numpy()
+        if md == "f32":
+            tol = 2e-5 + np.abs(ref_feat) * 2.0 ** -15
+            assert not (np.abs(feats - ref_feat) > tol).any(), float(np.abs(feats - ref_feat).max())
+            assert np.abs(sdf - ref_sdf).max() < 1e-4
+        else:
+            assert np.abs(feats - ref_feat).max() < 2e-3 * max(1.0, np.abs(ref_feat).max())
+            assert np.abs(sdf - ref_sdf).max() < 2e-3
+
+
 # ------------------------------------------------------------------------------------------ fused path
 @pytest.mark.parametrize("name", cases.CASE_NAMES)
 def test_fused_sdf_matches_reference(hip, golden_dir, name):
