@@ -506,6 +506,19 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
     (void)hipEventDestroy(ev);                    // released once the wait has been satisfied
     return err;
   };
+  // The bias / fc_out.weight column sums feed nothing downstream: forked, they leave the chain of dependent GEMMs
+  // and run on the atomics' stream, which has nothing to do until dX exists (same kernels, same order among
+  // themselves -- they share the `colsum` scratch).
+  auto side_colsum = [&](const unsigned short* z_hi, const unsigned short* z_lo, int N, const float* gsdf,
+                         const int* ord, int use_inv_scale, float* out) -> hipError_t {
+    hipStream_t to = s;
+    if (forked) {
+      const hipError_t err = hand_over(s, s_direct);
+      if (err != hipSuccess) return err;
+      to = s_direct;
+    }
+    return launch_colsum(z_hi, z_lo, crow, n_valid, N, fmt, gsdf, ord, scale, use_inv_scale, colsum, out, to);
+  };
   ScatterParams sp;
   sp.g = make_gather(a, L, ws, 0, n_valid, crow);
   sp.g.order = order;
@@ -532,11 +545,11 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   LIST_TRY(launch_head(ga->grad_sdf, order, n_valid, crow, a->H3, plane(bw.h3_hi), (const float*)(wp + pk.w3),
                        scale, plane(bw.dz3_hi), lo ? plane(bw.dz3_lo) : nullptr, fmt, s), "head launch");
   if (ga->mlp.w3)
-    LIST_TRY(launch_colsum(plane(bw.h3_hi), lo ? plane(bw.h3_lo) : nullptr, crow, n_valid, a->H3, fmt,
-                           ga->grad_sdf, order, scale, 0, colsum, ga->mlp.w3, s), "d fc_out.weight launch");
+    LIST_TRY(side_colsum(plane(bw.h3_hi), lo ? plane(bw.h3_lo) : nullptr, a->H3, ga->grad_sdf, order, 0, ga->mlp.w3),
+             "d fc_out.weight launch");
   if (ga->mlp.b2)
-    LIST_TRY(launch_colsum(plane(bw.dz3_hi), lo ? plane(bw.dz3_lo) : nullptr, crow, n_valid, a->H3, fmt, nullptr,
-                           nullptr, scale, 1, colsum, ga->mlp.b2, s), "d fc_2.bias launch");
+    LIST_TRY(side_colsum(plane(bw.dz3_hi), lo ? plane(bw.dz3_lo) : nullptr, a->H3, nullptr, nullptr, 1, ga->mlp.b2),
+             "d fc_2.bias launch");
   mark(LIST_BWD_HEAD);
 
   // one layer of the chain: weight gradient (TN), bias gradient, then the masked data gradient (NT)
@@ -578,8 +591,8 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   mark(LIST_BWD_DGRAD2);
   // fc_1
   if (ga->mlp.b1)
-    LIST_TRY(launch_colsum(plane(bw.dz2_hi), lo ? plane(bw.dz2_lo) : nullptr, crow, n_valid, a->H2, fmt, nullptr,
-                           nullptr, scale, 1, colsum, ga->mlp.b1, s), "d fc_1.bias launch");
+    LIST_TRY(side_colsum(plane(bw.dz2_hi), lo ? plane(bw.dz2_lo) : nullptr, a->H2, nullptr, nullptr, 1, ga->mlp.b1),
+             "d fc_1.bias launch");
   LIST_TRY(wgrad(bw.dz2_hi, bw.dz2_lo, a->H2, fw + ws.h1_hi, fw + ws.h1_lo, a->H1, a->H1, nullptr, ga->mlp.w1,
                  a->H1, s), "dW1 launch");
   mark(LIST_BWD_WGRAD1);
@@ -588,14 +601,15 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   mark(LIST_BWD_DGRAD1);
   // fc_0
   if (ga->mlp.b0)
-    LIST_TRY(launch_colsum(plane(bw.dz1_hi), lo ? plane(bw.dz1_lo) : nullptr, crow, n_valid, a->H1, fmt, nullptr,
-                           nullptr, scale, 1, colsum, ga->mlp.b0, s), "d fc_0.bias launch");
+    LIST_TRY(side_colsum(plane(bw.dz1_hi), lo ? plane(bw.dz1_lo) : nullptr, a->H1, nullptr, nullptr, 1, ga->mlp.b0),
+             "d fc_0.bias launch");
   bool want_maps = ga->grad_img_map || ga->grad_trans_mat || ga->grad_percep_feat;
   for (int l = 0; l < LIST_N_VOX_LEVELS; ++l) want_maps = want_maps || ga->grad_vox[l].data;
   if (!want_maps) {
     LIST_TRY(wgrad(bw.dz1_hi, bw.dz1_lo, a->H1, fw + ws.x_hi, fw + ws.x_lo, L.Kp, L.Kp, &L, ga->mlp.w0, L.F, s),
              "dW0 launch");
     for (int st = LIST_BWD_DGRAD0; st < LIST_N_BWD_STAGES; ++st) mark(st);
+    LIST_TRY(hand_over(s_direct, s), "stream join");
     return LIST_OK;
   }
   {
