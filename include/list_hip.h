@@ -283,7 +283,7 @@ typedef struct ListQueryGradArgs {
 enum ListBwdStage {
   LIST_BWD_BEGIN = 0,
   LIST_BWD_HEAD = 1,      /* scale, fc_2 re-evaluation, d(fc_out), bias/w3 sums */
-  LIST_BWD_WGRAD2 = 2,    /* k_gemm_tn: dW2 */
+  LIST_BWD_WGRAD2 = 2,    /* k_gemm_tn: dW2 (enqueue time only when forked, like WGRAD1 / WGRAD0) */
   LIST_BWD_DGRAD2 = 3,    /* k_gemm_nt: dH2 (masked) */
   LIST_BWD_WGRAD1 = 4,
   LIST_BWD_DGRAD1 = 5,

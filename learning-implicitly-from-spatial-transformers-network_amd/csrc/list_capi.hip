@@ -583,8 +583,11 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   };
 
   // fc_2
+  // (forked: the weight gradients feed nothing downstream either -- they queue up on the window stream, in the order
+  // dW2, dW1, dW0 because they share the split-K slab, while the data-gradient chain continues on `s`)
+  if (forked && ga->mlp.w2) LIST_TRY(hand_over(s, s_window), "stream fork");
   LIST_TRY(wgrad(bw.dz3_hi, bw.dz3_lo, a->H3, fw + ws.h2_hi, fw + ws.h2_lo, a->H2, a->H2, nullptr, ga->mlp.w2,
-                 a->H2, s), "dW2 launch");
+                 a->H2, s_window), "dW2 launch");
   mark(LIST_BWD_WGRAD2);
   LIST_TRY(dgrad(bw.dz3_hi, bw.dz3_lo, a->H3, wt + pb.w2t_hi, wt + pb.w2t_lo, a->H2, fw + ws.h2_hi, bw.dz2_hi,
                  bw.dz2_lo), "dH2 launch");
@@ -593,8 +596,9 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   if (ga->mlp.b1)
     LIST_TRY(side_colsum(plane(bw.dz2_hi), lo ? plane(bw.dz2_lo) : nullptr, a->H2, nullptr, nullptr, 1, ga->mlp.b1),
              "d fc_1.bias launch");
+  if (forked && ga->mlp.w1) LIST_TRY(hand_over(s, s_window), "stream fork");
   LIST_TRY(wgrad(bw.dz2_hi, bw.dz2_lo, a->H2, fw + ws.h1_hi, fw + ws.h1_lo, a->H1, a->H1, nullptr, ga->mlp.w1,
-                 a->H1, s), "dW1 launch");
+                 a->H1, s_window), "dW1 launch");
   mark(LIST_BWD_WGRAD1);
   LIST_TRY(dgrad(bw.dz2_hi, bw.dz2_lo, a->H2, wt + pb.w1t_hi, wt + pb.w1t_lo, a->H1, fw + ws.h1_hi, bw.dz1_hi,
                  bw.dz1_lo), "dH1 launch");
@@ -606,6 +610,7 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   bool want_maps = ga->grad_img_map || ga->grad_trans_mat || ga->grad_percep_feat;
   for (int l = 0; l < LIST_N_VOX_LEVELS; ++l) want_maps = want_maps || ga->grad_vox[l].data;
   if (!want_maps) {
+    LIST_TRY(hand_over(s_window, s), "stream join");            // dW0 shares the slab with dW2 / dW1
     LIST_TRY(wgrad(bw.dz1_hi, bw.dz1_lo, a->H1, fw + ws.x_hi, fw + ws.x_lo, L.Kp, L.Kp, &L, ga->mlp.w0, L.F, s),
              "dW0 launch");
     for (int st = LIST_BWD_DGRAD0; st < LIST_N_BWD_STAGES; ++st) mark(st);
