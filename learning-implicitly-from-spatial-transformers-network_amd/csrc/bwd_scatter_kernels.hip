@@ -306,46 +306,65 @@ __global__ __launch_bounds__(256) void k_vs_hist(ScatterParams sp, ListVoxLevel 
   keys[t] = cell;
 }
 
-// in-place exclusive scan of n ints: per-block scan + block totals, scan of the totals, add back
-__global__ __launch_bounds__(1024) void k_scan_block(int* __restrict__ a, int n, int* __restrict__ sums) {
-  __shared__ int part[1024];
-  const int i0 = blockIdx.x * kScanPerBlock + threadIdx.x * 4;
+// in-place exclusive scan of n ints: per-block scan + block totals, scan of the totals, add back.  256-thread
+// workgroups (16 consecutive ints per thread, wave scans by shuffles, one barrier): beside the backward's other streams
+// a 1024-thread workgroup waits for a CU with four free wave slots per SIMD (the three launches took 0.6 ms there for
+// 1 MB of counters; 0.03 ms alone).
+constexpr int kScanThreads = 256, kScanPerThread = kScanPerBlock / kScanThreads;
+
+// exclusive prefix of `sum` over the workgroup's threads; the workgroup total in `total`
+__device__ __forceinline__ int block_exclusive(int sum, int* wave_tot, int& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int u = __shfl_up(inc, off);
+    if (lane >= off) inc += u;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  int before = 0;
+  total = 0;
+#pragma unroll
+  for (int w = 0; w < kScanThreads / 64; ++w) {
+    const int t = wave_tot[w];
+    if (w < wave) before += t;
+    total += t;
+  }
+  return before + inc - sum;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_block(int* __restrict__ a, int n, int* __restrict__ sums) {
+  __shared__ int wave_tot[kScanThreads / 64];
+  const int i0 = blockIdx.x * kScanPerBlock + threadIdx.x * kScanPerThread;
+  int v[kScanPerThread], sum = 0;
+#pragma unroll
+  for (int e = 0; e < kScanPerThread; ++e) { v[e] = (i0 + e < n) ? a[i0 + e] : 0; sum += v[e]; }
+  int total;
+  int run = block_exclusive(sum, wave_tot, total);
+#pragma unroll
+  for (int e = 0; e < kScanPerThread; ++e) { if (i0 + e < n) a[i0 + e] = run; run += v[e]; }
+  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// nb <= 1024 block totals (kVoxGatherMaxBins / kScanPerBlock), one workgroup, 4 per thread
+__global__ __launch_bounds__(kScanThreads) void k_scan_sums(int* __restrict__ sums, int nb) {
+  __shared__ int wave_tot[kScanThreads / 64];
+  const int i0 = threadIdx.x * 4;
   int v[4], sum = 0;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { v[e] = (i0 + e < n) ? a[i0 + e] : 0; sum += v[e]; }
-  part[threadIdx.x] = sum;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    const int u = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-    __syncthreads();
-    part[threadIdx.x] += u;
-    __syncthreads();
-  }
-  int run = part[threadIdx.x] - sum;
+  for (int e = 0; e < 4; ++e) { v[e] = (i0 + e < nb) ? sums[i0 + e] : 0; sum += v[e]; }
+  int total;
+  int run = block_exclusive(sum, wave_tot, total);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { if (i0 + e < n) a[i0 + e] = run; run += v[e]; }
-  if (threadIdx.x == 1023) sums[blockIdx.x] = part[1023];
+  for (int e = 0; e < 4; ++e) { if (i0 + e < nb) sums[i0 + e] = run; run += v[e]; }
 }
 
-__global__ __launch_bounds__(1024) void k_scan_sums(int* __restrict__ sums, int nb) {
-  __shared__ int part[1024];
-  const int v = (int)threadIdx.x < nb ? sums[threadIdx.x] : 0;
-  part[threadIdx.x] = v;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    const int u = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-    __syncthreads();
-    part[threadIdx.x] += u;
-    __syncthreads();
-  }
-  if ((int)threadIdx.x < nb) sums[threadIdx.x] = part[threadIdx.x] - v;
-}
-
-__global__ __launch_bounds__(1024) void k_scan_add(int* __restrict__ a, int n, const int* __restrict__ sums) {
-  const int i0 = blockIdx.x * kScanPerBlock + threadIdx.x * 4;
+__global__ __launch_bounds__(kScanThreads) void k_scan_add(int* __restrict__ a, int n, const int* __restrict__ sums) {
+  const int i0 = blockIdx.x * kScanPerBlock + threadIdx.x * kScanPerThread;
   const int add = sums[blockIdx.x];
 #pragma unroll
-  for (int e = 0; e < 4; ++e)
+  for (int e = 0; e < kScanPerThread; ++e)
     if (i0 + e < n) a[i0 + e] += add;
 }
 
@@ -426,9 +445,9 @@ static hipError_t gather_level(const ScatterParams& sp, const ListVoxLevel& gv, 
   if (e != hipSuccess) return e;
   const dim3 gs((unsigned)((sp.g.rows * 8 + 255) / 256));
   hipLaunchKernelGGL(k_vs_hist, gs, dim3(256), 0, s, sp, gv, vb.keys, vb.bins);
-  hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nb), dim3(1024), 0, s, vb.bins, (int)n_vox, vb.sums);
-  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, vb.sums, nb);
-  hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(1024), 0, s, vb.bins, (int)n_vox, vb.sums);
+  hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nb), dim3(kScanThreads), 0, s, vb.bins, (int)n_vox, vb.sums);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, s, vb.sums, nb);
+  hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(kScanThreads), 0, s, vb.bins, (int)n_vox, vb.sums);
   hipLaunchKernelGGL(k_vs_scatter<C>, gs, dim3(256), 0, s, sp, gv, vb.keys, vb.bins, (VoxSample*)vb.recs, col_off);
   const dim3 gg((unsigned)((n_vox + 256 / C - 1) / (256 / C)));
   if (sp.dx_f16)
