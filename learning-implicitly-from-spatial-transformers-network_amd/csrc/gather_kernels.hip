@@ -344,7 +344,7 @@ __global__ __launch_bounds__(1024) void k_sort_scan(int* __restrict__ bins_m, in
   part[threadIdx.x] = sum;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {
-    const int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+    const int v = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
     __syncthreads();
     part[threadIdx.x] += v;
     __syncthreads();
