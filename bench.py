@@ -139,6 +139,7 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
     sdfs = [torch.empty((B, N), dtype=torch.float32, device=device) for _ in range(2 if world > 1 else 1)]
     pending = [None, None]
     n_calls = [0]
+    overlap_exchange = [True]
 
     def step(events=None):
         pre, arr = events if events else (None, None)
@@ -159,7 +160,14 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
         hip.sdf_query(inp["query"], inp["trans_mat"], img, vox, packed, precision=precision,
                       out=sdf, stage_events=arr, clamp_hi=inp["clamp_hi"])
         if world > 1:
-            _, pending[k] = gather_fn(sdf, out=gathered[k], async_op=True)
+            if overlap_exchange[0]:
+                try:
+                    _, pending[k] = gather_fn(sdf, out=gathered[k], async_op=True)
+                except (RuntimeError, TypeError) as e:          # no work handle from this backend build: in-line exchange
+                    overlap_exchange[0] = False
+                    print(f"bench: asynchronous all-gather unavailable ({e}); exchanging in line", file=sys.stderr)
+            if not overlap_exchange[0]:
+                gather_fn(sdf, out=gathered[k])
         return sdf
 
     def drain():
