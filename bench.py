@@ -298,6 +298,10 @@ def run_whole_model(workload, precision, device, steps=5, warmup=2):
                     times["query"] += t2 - t1
         total = (times["encode"] + times["query"]) / steps
         return net, sdf, {"ms_per_forward": total * 1e3, "value": B * N / total,
+                          # SURVEY 8d's second run: the query path fed by the model's own (untrained) spatial transformer
+                          # and encoders instead of the synthetic camera and maps
+                          "query_path_points_per_s": B * N / (times["query"] / steps),
+                          "trans_mat": "output of the model's own untrained spatial_transformer",
                           "encode_ms": times["encode"] / steps * 1e3, "query_sdf_ms": times["query"] / steps * 1e3,
                           "finite": bool(torch.isfinite(sdf).all())}
 
