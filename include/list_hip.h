@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LIST_ABI_VERSION 3
+#define LIST_ABI_VERSION 4
 
 #define LIST_N_IMG_LEVELS 5   /* ResEncoder feature maps, network/modules.py:1067 */
 #define LIST_N_VOX_LEVELS 6   /* VoxelEncoder2 feature maps, network/modules.py:425-442 */
@@ -146,7 +146,8 @@ typedef struct ListQueryArgs {
   int32_t img_dtype;                    /* enum ListMapDtype of img_map */
   int32_t map_size;                     /* 137 */
   int32_t img_C;                        /* 1024 */
-  float clamp_hi;                       /* 136.0 (hard-coded in modules.py:43) */
+  float clamp_hi;                       /* 136.0 (hard-coded in modules.py:43); samples beyond  */
+                                        /*   map_size-1 read zeros (grid_sample zeros padding)   */
   const float* percep_feat;             /* optional pre-pooled features [B,img_C,N] instead of */
   int64_t pf_sb, pf_sc, pf_sn;          /*   img_map (VoxelDecoder2.forward's 3rd argument) */
   ListVoxLevel vox[LIST_N_VOX_LEVELS];  /* from list_prep_vox_maps */
@@ -155,15 +156,21 @@ typedef struct ListQueryArgs {
   float* sdf;                           /* [B,N] contiguous, output */
   void* workspace; size_t workspace_bytes;   /* >= list_query_workspace_bytes(B*N) */
   int32_t precision;                    /* enum ListPrecision */
-  void* const* stage_events;            /* optional: LIST_N_STAGES hipEvent_t handles (host array), */
-                                        /*   recorded on the stream at the stage boundaries below   */
+  void* const* stage_events;            /* optional: stage_event_sets x LIST_N_STAGES hipEvent_t    */
+                                        /*   handles (host array), recorded on the stream at the    */
+                                        /*   stage boundaries below; set c belongs to row chunk c   */
   int32_t no_sort;                      /* 0: process points in Morton order (default; results are  */
                                         /*   bit-identical either way), 1: keep the caller's order  */
+  int32_t stage_event_sets;             /* number of event sets behind stage_events (0 counts as 1): */
+                                        /*   row chunk c records into set c, chunks beyond the last  */
+                                        /*   set record nothing.  list_query_chunk_rows() tells how  */
+                                        /*   many chunks a call takes                                */
 } ListQueryArgs;
 
 /* Boundaries recorded into ListQueryArgs.stage_events: one hipEvent after each kernel (group) of a
- * row chunk, so that the interval [i-1, i] is the duration of kernel i.  A later chunk re-records,
- * so time single-chunk calls. */
+ * row chunk, so that the interval [i-1, i] of a set is the duration of kernel i for that chunk.  A query
+ * above the chunk size runs ceil(B*N / list_query_chunk_rows()) chunks back to back: give one set per
+ * chunk and sum the intervals over the sets for the time of the whole call. */
 enum ListStage {
   LIST_STAGE_BEGIN = 0,   /* before the first kernel */
   LIST_STAGE_SORT = 1,    /* point ordering (histogram / scan / scatter, two passes) */
@@ -181,6 +188,10 @@ enum ListStage {
 };
 
 size_t list_query_workspace_bytes(int64_t n_points, int32_t F, int32_t H1, int32_t H2, int32_t H3);
+/* rows (query points) one chunk of list_sdf_query_fwd processes with a workspace of `workspace_bytes`
+ * (a multiple of 256, at most 262144 and at most n_points rounded up to 256); 0 if nothing fits. */
+int64_t list_query_chunk_rows(size_t workspace_bytes, int64_t n_points, int32_t F, int32_t H1, int32_t H2,
+                              int32_t H3);
 int list_sdf_query_fwd(const ListQueryArgs* args, void* stream);
 
 /* ---------------------------------------------------------------------------------------

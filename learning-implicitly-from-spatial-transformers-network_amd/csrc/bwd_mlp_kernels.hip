@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void k_prep_wt(const float* __restrict__ w, in
   } else {
     const unsigned short h = f2bf(v);
     hi[i] = h;
-    lo[i] = f2bf(v - bf2f(h));
+    lo[i] = bf_lo(v, h);
   }
 }
 

@@ -54,6 +54,47 @@ __device__ __forceinline__ void tap_fma(const typename M::Raw& r, float w, float
   for (int c = 0; c < M::V; ++c) a[c] = fmaf(f[c], w, a[c]);
 }
 
+// ---- exact border semantics (cold path) -----------------------------------------------------------------
+// The fast reductions multiply a tap the reference SKIPS (index == size under border padding, outside the map
+// under zeros padding) by its exactly-zero weight.  That is the same number unless the voxel read in its place
+// holds +-inf or NaN (0 * inf = NaN where the reference adds nothing).  Every gather therefore probes its result
+// for NaN.  The voxel gathers flag the 64-row group of such a row (GatherParams.nan_flags) and k_gather_fixup,
+// launched behind them, redoes flagged groups with the skipped taps' VALUES forced to zero; the 2-D gather and
+// the scalar tail re-reduce in place.  None of this runs on finite maps (one predicated store and one
+// 1-workgroup-per-64-rows launch that reads a flag and exits).
+template <int V>
+__device__ __forceinline__ bool any_nan(const float (&a)[V]) {
+  bool bad = false;
+#pragma unroll
+  for (int c = 0; c < V; ++c) bad = bad || (a[c] != a[c]);
+  return bad;
+}
+__device__ __forceinline__ bool wave_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0; }
+// The cold paths take their inputs through an opaque move: without it the compiler shares sub-expressions
+// (unpacked taps, tap geometry) between the fast and the cold reduction and keeps them live across the fast
+// one -- measured in registers: k_gather_vox<16> 36 -> 160 VGPRs, the shared-tap kernel 104 -> 256.
+__device__ __forceinline__ void launder(float& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void launder(int& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void launder(unsigned& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void launder(float4& r) { launder(r.x); launder(r.y); launder(r.z); launder(r.w); }
+__device__ __forceinline__ void launder(uint4& r) { launder(r.x); launder(r.y); launder(r.z); launder(r.w); }
+
+template <typename M>
+__device__ __forceinline__ void tap_fma_masked(typename M::Raw r, float w, bool dead, float (&a)[M::V]) {
+  float f[M::V];
+  launder(r);
+  M::unpack(r, f);
+#pragma unroll
+  for (int c = 0; c < M::V; ++c) a[c] = fmaf(dead ? 0.f : f[c], w, a[c]);
+}
+template <typename M>
+__device__ __forceinline__ void reduce_taps_exact(const typename M::Raw (&v)[8], const Taps& t, float (&acc)[M::V]) {
+#pragma unroll
+  for (int c = 0; c < M::V; ++c) acc[c] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) tap_fma_masked<M>(v[k], t.w[k], (t.dead >> k) & 1, acc);   // (tap 0 is never skipped)
+}
+
 // store V consecutive features of one row of X
 template <int FMT, int V>
 __device__ __forceinline__ void store_feats(unsigned short* __restrict__ xh, unsigned short* __restrict__ xl,
@@ -76,7 +117,7 @@ __device__ __forceinline__ void reduce_taps(const typename M::Raw (&v)[8], const
 // Two stencil points at a time: all 16 tap loads are issued before the first use, so a wave has
 // 16 KB in flight per step instead of one dependent 8-load round trip per stencil point.
 template <int C, int J0, int J1, int FMT, typename M>
-__device__ __forceinline__ void gather_pair(const ListVoxLevel& lv, const void* __restrict__ base,
+__device__ __forceinline__ bool gather_pair(const ListVoxLevel& lv, const void* __restrict__ base,
                                             int64_t boff, const Pt& p, unsigned short* __restrict__ xh,
                                             unsigned short* __restrict__ xl, int64_t out_off) {
   float x0, y0, z0, x1, y1, z1;
@@ -93,11 +134,14 @@ __device__ __forceinline__ void gather_pair(const ListVoxLevel& lv, const void* 
   }
   float r[M::V];
   reduce_taps<M>(v0, t0, r);
+  bool bad = any_nan<M::V>(r);
   store_feats<FMT, M::V>(xh, xl, out_off + J0 * C, r, p.valid);
   if (J1 != J0) {
     reduce_taps<M>(v1, t1, r);
+    bad = bad || any_nan<M::V>(r);
     store_feats<FMT, M::V>(xh, xl, out_off + J1 * C, r, p.valid);
   }
+  return bad;
 }
 
 // grid = rows/RB, block = 256.  LP = C/V lanes share a point; a wave covers 64/LP points.  The
@@ -129,10 +173,11 @@ __global__ __launch_bounds__(256) void k_gather_vox(GatherParams g, ListVoxLevel
     const Pt p = pts[local];
     const int64_t boff = (int64_t)p.b * lv.image_stride + sub * M::V;
     const int64_t out_off = (int64_t)row * g.Kp + col_off + sub * M::V;
-    gather_pair<C, 0, 1, FMT, M>(lv, lv.data, boff, p, xh, xl, out_off);
-    gather_pair<C, 2, 3, FMT, M>(lv, lv.data, boff, p, xh, xl, out_off);
-    gather_pair<C, 4, 5, FMT, M>(lv, lv.data, boff, p, xh, xl, out_off);
-    gather_pair<C, 6, 6, FMT, M>(lv, lv.data, boff, p, xh, xl, out_off);
+    bool bad = gather_pair<C, 0, 1, FMT, M>(lv, lv.data, boff, p, xh, xl, out_off);
+    bad |= gather_pair<C, 2, 3, FMT, M>(lv, lv.data, boff, p, xh, xl, out_off);
+    bad |= gather_pair<C, 4, 5, FMT, M>(lv, lv.data, boff, p, xh, xl, out_off);
+    bad |= gather_pair<C, 6, 6, FMT, M>(lv, lv.data, boff, p, xh, xl, out_off);
+    if (bad) g.nan_flags[row >> 6] = 1;
   }
 }
 
@@ -160,7 +205,7 @@ __device__ __forceinline__ void plane4(const typename M::Raw& a, const typename 
 }
 
 template <int FMT, int V>
-__device__ __forceinline__ void store_wsum(const float (&P)[4][V], const float (&w)[4],
+__device__ __forceinline__ bool store_wsum(const float (&P)[4][V], const float (&w)[4],
                                            unsigned short* __restrict__ xh, unsigned short* __restrict__ xl,
                                            int64_t off, bool valid) {
   float r[V];
@@ -171,6 +216,7 @@ __device__ __forceinline__ void store_wsum(const float (&P)[4][V], const float (
     r[c] = t;
   }
   store_feats<FMT, V>(xh, xl, off, r, valid);
+  return any_nan<V>(r);
 }
 
 template <int C, int FMT, int F16>
@@ -246,23 +292,26 @@ __global__ __launch_bounds__(256) void k_gather_vox_near(GatherParams g, ListVox
     // x axis -> stencil points 0, 1, 2
 #pragma unroll
     for (int k = 0; k < 4; ++k) plane4<M>(A[k][0], A[k][1], A[k][2], A[k][3], wyz, P[k]);
-    store_wsum<FMT, V>(P, wcx, xh, xl, out_off + 0 * C, p.valid);
-    store_wsum<FMT, V>(P, wmx, xh, xl, out_off + 1 * C, p.valid);
-    store_wsum<FMT, V>(P, wpx, xh, xl, out_off + 2 * C, p.valid);
+    bool bad = store_wsum<FMT, V>(P, wcx, xh, xl, out_off + 0 * C, p.valid);
+    bad |= store_wsum<FMT, V>(P, wmx, xh, xl, out_off + 1 * C, p.valid);
+    bad |= store_wsum<FMT, V>(P, wpx, xh, xl, out_off + 2 * C, p.valid);
     // y axis: planes 1,2 come from A (x slots 1,2), planes 0,3 from By; weights (x1,z1)(x2,z1)(x1,z2)(x2,z2)
     plane4<M>(By[0][0], By[0][1], By[0][2], By[0][3], wxz, P[0]);
     plane4<M>(A[1][0], A[2][0], A[1][2], A[2][2], wxz, P[1]);
     plane4<M>(A[1][1], A[2][1], A[1][3], A[2][3], wxz, P[2]);
     plane4<M>(By[1][0], By[1][1], By[1][2], By[1][3], wxz, P[3]);
-    store_wsum<FMT, V>(P, wmy, xh, xl, out_off + 3 * C, p.valid);
-    store_wsum<FMT, V>(P, wpy, xh, xl, out_off + 4 * C, p.valid);
+    bad |= store_wsum<FMT, V>(P, wmy, xh, xl, out_off + 3 * C, p.valid);
+    bad |= store_wsum<FMT, V>(P, wpy, xh, xl, out_off + 4 * C, p.valid);
     // z axis: planes 1,2 from A, planes 0,3 from Bz; weights (x1,y1)(x2,y1)(x1,y2)(x2,y2)
     plane4<M>(Bz[0][0], Bz[0][1], Bz[0][2], Bz[0][3], wxy, P[0]);
     plane4<M>(A[1][0], A[2][0], A[1][1], A[2][1], wxy, P[1]);
     plane4<M>(A[1][2], A[2][2], A[1][3], A[2][3], wxy, P[2]);
     plane4<M>(Bz[1][0], Bz[1][1], Bz[1][2], Bz[1][3], wxy, P[3]);
-    store_wsum<FMT, V>(P, wmz, xh, xl, out_off + 5 * C, p.valid);
-    store_wsum<FMT, V>(P, wpz, xh, xl, out_off + 6 * C, p.valid);
+    bad |= store_wsum<FMT, V>(P, wmz, xh, xl, out_off + 5 * C, p.valid);
+    bad |= store_wsum<FMT, V>(P, wpz, xh, xl, out_off + 6 * C, p.valid);
+    // a NaN anywhere (a window voxel with weight 0 holding +-inf / NaN poisons the shared sums): redo the wave's
+    // points sample by sample with the reference's skip semantics; the rows are rewritten by the same lanes
+    if (bad) g.nan_flags[row >> 6] = 1;
   }
 }
 
@@ -411,6 +460,15 @@ hipError_t launch_sort_points(const GatherParams& g, const ListQueryArgs& a, con
 // -> trans_mat per workgroup), then two points (8 x 16-B loads per lane) are in flight per step.
 struct ImgPoint { Proj pr; int row; int b; int valid; };
 
+// zeros padding as ATen's CPU kernel evaluates it: an out-of-map tap reads 0 and is still multiplied by its weight
+template <typename M>
+__device__ __forceinline__ void reduce_proj_exact(const typename M::Raw (&v)[4], const Proj& pr, float (&r)[M::V]) {
+#pragma unroll
+  for (int c = 0; c < M::V; ++c) r[c] = 0.f;
+  tap_fma_masked<M>(v[0], pr.w00, pr.dead & 1, r); tap_fma_masked<M>(v[1], pr.w01, (pr.dead >> 1) & 1, r);
+  tap_fma_masked<M>(v[2], pr.w10, (pr.dead >> 2) & 1, r); tap_fma_masked<M>(v[3], pr.w11, (pr.dead >> 3) & 1, r);
+}
+
 template <int FMT, int F16>
 __global__ __launch_bounds__(256) void k_gather_img(GatherParams g, const void* __restrict__ img_map,
                                                     const float* __restrict__ trans_mat, int ms,
@@ -471,6 +529,7 @@ __global__ __launch_bounds__(256) void k_gather_img(GatherParams g, const void* 
         float r[M::V];
         tap_mul<M>(v[k][0], a.pr.w00, r); tap_fma<M>(v[k][1], a.pr.w01, r);
         tap_fma<M>(v[k][2], a.pr.w10, r); tap_fma<M>(v[k][3], a.pr.w11, r);
+        if (wave_any(any_nan<M::V>(r))) reduce_proj_exact<M>(v[k], a.pr, r);
         store_feats<FMT, M::V>(xh, xl, (int64_t)a.row * g.Kp + col_off + q * M::V, r, a.valid != 0);
       }
     }
@@ -535,7 +594,13 @@ __global__ __launch_bounds__(256) void k_gather_tail(GatherParams g, TailLevels 
       float v[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] = base[tp.o[k]];
-      put<FMT>(g, ro + tl.off[l] + j, p.valid ? reduce_taps1(v, tp) : 0.f);
+      float r = reduce_taps1(v, tp);
+      if (r != r) {                             // see reduce_taps_exact (per lane here: one sample per lane)
+        r = v[0] * tp.w[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) r = fmaf(((tp.dead >> k) & 1) ? 0.f : v[k], tp.w[k], r);
+      }
+      put<FMT>(g, ro + tl.off[l] + j, p.valid ? r : 0.f);
     }
     return;
   }
@@ -553,6 +618,47 @@ __global__ __launch_bounds__(256) void k_gather_tail(GatherParams g, TailLevels 
   };
   zero_pad(g.x_hi);
   if (FMT == FMT_BF16_SPLIT) zero_pad(g.x_lo);
+}
+
+// ---- exact redo of flagged row groups (cold) ---------------------------------------------------------------
+struct FixupLevels { ListVoxLevel lv[LIST_N_VOX_LEVELS]; int off[LIST_N_VOX_LEVELS]; int n; };
+
+template <int FMT, typename M>
+__device__ __forceinline__ void fixup_level(const GatherParams& g, const ListVoxLevel& lv, int col_off, int blk,
+                                            const Pt* pts) {
+  const int C = lv.C, lp = C / M::V;
+  for (int item = threadIdx.x; item < kGatherRows * lp; item += 256) {
+    const int local = item / lp, sub = item - local * lp;
+    const Pt p = pts[local];
+    const int64_t boff = (int64_t)p.b * lv.image_stride + sub * M::V;
+    const int64_t out_off = (int64_t)(blk * kGatherRows + local) * g.Kp + col_off + sub * M::V;
+#pragma unroll 1
+    for (int j = 0; j < LIST_N_STENCIL; ++j) {
+      const float x = p.x + (j == 1 ? -kDisp : j == 2 ? kDisp : 0.f);
+      const float y = p.y + (j == 3 ? -kDisp : j == 4 ? kDisp : 0.f);
+      const float z = p.z + (j == 5 ? -kDisp : j == 6 ? kDisp : 0.f);
+      const Taps t = make_taps(x, y, z, C, lv.D, lv.H, lv.W);
+      typename M::Raw v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = M::load(lv.data, boff + t.o[k]);
+      float r[M::V];
+      reduce_taps_exact<M>(v, t, r);
+      store_feats<FMT, M::V>(g.x_hi, g.x_lo, out_off + j * C, r, p.valid);
+    }
+  }
+}
+
+template <int FMT>
+__global__ __launch_bounds__(256) void k_gather_fixup(GatherParams g, FixupLevels fl) {
+  __shared__ Pt pts[kGatherRows];
+  const int blk = blockIdx.x;
+  if (g.nan_flags[blk] == 0) return;
+  if (threadIdx.x < kGatherRows) pts[threadIdx.x] = load_point(g, blk * kGatherRows + threadIdx.x);
+  __syncthreads();
+  for (int l = 0; l < fl.n; ++l) {
+    if (fl.lv[l].dtype == LIST_MAP_F16) fixup_level<FMT, MapT<1>>(g, fl.lv[l], fl.off[l], blk, pts);
+    else fixup_level<FMT, MapT<0>>(g, fl.lv[l], fl.off[l], blk, pts);
+  }
 }
 
 // ---- launch ----------------------------------------------------------------------------------------
@@ -589,9 +695,14 @@ static hipError_t launch_gather_fmt(const GatherParams& g, const FeatLayout& L, 
   int vec_level = 0;
   TailLevels tl;
   tl.n = 0;
+  FixupLevels fl;
+  fl.n = 0;
+  e = hipMemsetAsync(g.nan_flags, 0, (size_t)(g.rows / kGatherRows) * sizeof(int), s);
+  if (e != hipSuccess) return e;
   for (int l = 0; l < LIST_N_VOX_LEVELS; ++l) {
     const ListVoxLevel& lv = a.vox[l];
     if (lv.C == 1) { tl.lv[tl.n] = lv; tl.off[tl.n] = L.vox_off[l]; ++tl.n; continue; }
+    fl.lv[fl.n] = lv; fl.off[fl.n] = L.vox_off[l]; ++fl.n;
     switch (lv.C) {
       case 4: e = launch_vox_level<4, FMT>(g, lv, L.vox_off[l], s); break;
       case 8: e = launch_vox_level<8, FMT>(g, lv, L.vox_off[l], s); break;
@@ -622,6 +733,8 @@ static hipError_t launch_gather_fmt(const GatherParams& g, const FeatLayout& L, 
   mark(LIST_STAGE_IMG);
   hipLaunchKernelGGL(k_gather_tail<FMT>, dim3((g.rows + 31) / 32), dim3(256), 0, s, g, tl, L.xyz_off,
                      L.F);
+  if (fl.n > 0)
+    hipLaunchKernelGGL(k_gather_fixup<FMT>, dim3(g.rows / kGatherRows), dim3(256), 0, s, g, fl);
   return hipGetLastError();
 }
 
@@ -672,10 +785,11 @@ __global__ __launch_bounds__(256) void k_percep_pool(ListPoolArgs a) {
   float* o = a.out + (int64_t)b * a.img_C * a.N + n;
   for (int c = 0; c < a.img_C; c += M::V) {
     float r[M::V];
-    tap_mul<M>(M::load(a.img_map, bo + pr.o00 + c), pr.w00, r);
-    tap_fma<M>(M::load(a.img_map, bo + pr.o01 + c), pr.w01, r);
-    tap_fma<M>(M::load(a.img_map, bo + pr.o10 + c), pr.w10, r);
-    tap_fma<M>(M::load(a.img_map, bo + pr.o11 + c), pr.w11, r);
+    const typename M::Raw v[4] = {M::load(a.img_map, bo + pr.o00 + c), M::load(a.img_map, bo + pr.o01 + c),
+                                  M::load(a.img_map, bo + pr.o10 + c), M::load(a.img_map, bo + pr.o11 + c)};
+    tap_mul<M>(v[0], pr.w00, r); tap_fma<M>(v[1], pr.w01, r);
+    tap_fma<M>(v[2], pr.w10, r); tap_fma<M>(v[3], pr.w11, r);
+    if (any_nan<M::V>(r)) reduce_proj_exact<M>(v, pr, r);
 #pragma unroll
     for (int k = 0; k < M::V; ++k) o[(int64_t)(c + k) * a.N] = r[k];
   }

@@ -141,9 +141,13 @@ __device__ __forceinline__ void store8_planes(unsigned short* __restrict__ hi, u
   unsigned h[4], l[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const unsigned short h0 = to_half_plane<FP16>(v[2 * e]), h1 = to_half_plane<FP16>(v[2 * e + 1]);
-    h[e] = (unsigned)h0 | ((unsigned)h1 << 16);
-    if (!FP16) l[e] = (unsigned)f2bf(v[2 * e] - bf2f(h0)) | ((unsigned)f2bf(v[2 * e + 1] - bf2f(h1)) << 16);
+    if (FP16) {
+      h[e] = f2h2(v[2 * e], v[2 * e + 1]);
+    } else {
+      const unsigned short h0 = f2bf(v[2 * e]), h1 = f2bf(v[2 * e + 1]);
+      h[e] = (unsigned)h0 | ((unsigned)h1 << 16);
+      l[e] = (unsigned)bf_lo(v[2 * e], h0) | ((unsigned)bf_lo(v[2 * e + 1], h1) << 16);
+    }
   }
   *(uint4*)(hi + off) = make_uint4(h[0], h[1], h[2], h[3]);
   if (!FP16 && lo) *(uint4*)(lo + off) = make_uint4(l[0], l[1], l[2], l[3]);
@@ -194,7 +198,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
       const float4 b1 = p.bias ? *(const float4*)(p.bias + col_base + c8 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = fmaxf(v[e] + bb[e], 0.f);
+      for (int e = 0; e < 8; ++e) o[e] = relu_nan(v[e] + bb[e]);
       store8_planes<FP16>(p.out_hi, p.out_lo, (row_base + r) * p.ldo + col_base + c8, o);
     });
   } else if (EPI == EPI_RELU_SPLIT || EPI == EPI_F32) {
@@ -214,13 +218,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
           const int off = (i * 32 + (e & 3) + 8 * (e >> 2)) * ld + j * 32;
           float v = acc[i][j][e] + bias;
           if (EPI == EPI_F32) {
-            if (p.relu) v = fmaxf(v, 0.f);
+            if (p.relu) v = relu_nan(v);
             of[off] = v;
           } else {
-            v = fmaxf(v, 0.f);
+            v = relu_nan(v);
             const unsigned short h = to_half_plane<FP16>(v);
             oh[off] = h;
-            if (!FP16 && ol) ol[off] = f2bf(v - bf2f(h));
+            if (!FP16 && ol) ol[off] = bf_lo(v, h);
           }
         }
     }
@@ -238,7 +242,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) part[i][e] += fmaxf(acc[i][j][e] + bias, 0.f) * w3;
+        for (int e = 0; e < 16; ++e) part[i][e] += relu_nan(acc[i][j][e] + bias) * w3;
     }
     // reduce over the 32 lanes that hold the 32 columns of a row (xor < 32 stays inside a half)
 #pragma unroll
@@ -609,13 +613,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt16(GemmParams p) {
           const int off = (i * 16 + e) * ld + j * 16;
           float v = acc[i][j][e] + bias;
           if (EPI == EPI_F32) {
-            if (p.relu) v = fmaxf(v, 0.f);
+            if (p.relu) v = relu_nan(v);
             of[off] = v;
           } else {
-            v = fmaxf(v, 0.f);
+            v = relu_nan(v);
             const unsigned short h = to_half_plane<FP16>(v);
             oh[off] = h;
-            if (!FP16 && ol) ol[off] = f2bf(v - bf2f(h));
+            if (!FP16 && ol) ol[off] = bf_lo(v, h);
           }
         }
     }
@@ -632,7 +636,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt16(GemmParams p) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) part[i][e] += fmaxf(acc[i][j][e] + bias, 0.f) * w3;
+        for (int e = 0; e < 4; ++e) part[i][e] += relu_nan(acc[i][j][e] + bias) * w3;
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i)

@@ -83,6 +83,7 @@ int check_query_common(const ListQueryArgs* a, FeatLayout* L) {
     if (a->img_dtype == LIST_MAP_F16 && a->img_C % 8)
       return fail(LIST_ERR_UNSUPPORTED, "fp16 image map needs img_C %% 8 == 0");
     if (a->map_size < 2) return fail(LIST_ERR_SHAPE, "map_size=%d", a->map_size);
+    if (!(a->clamp_hi >= 0.f)) return fail(LIST_ERR_ARG, "clamp_hi=%g must be >= 0", (double)a->clamp_hi);
     if ((int64_t)a->map_size * a->map_size * a->img_C >= (int64_t)1 << 31)
       return fail(LIST_ERR_SHAPE, "image map larger than 2^31 elements");
   }
@@ -100,6 +101,7 @@ GatherParams make_gather(const ListQueryArgs* a, const FeatLayout& L, const Work
   g.Kp = L.Kp;
   g.fmt = a->precision == LIST_PREC_FP16 ? FMT_FP16 : FMT_BF16_SPLIT;
   g.order = nullptr; g.order_img = nullptr; g.row_of = nullptr;
+  g.nan_flags = (int*)((char*)a->workspace + ws.nan_flags);
   return g;
 }
 
@@ -256,6 +258,13 @@ size_t list_query_workspace_bytes(int64_t n_points, int32_t F, int32_t H1, int32
   return workspace_layout(rows, Kp, H1, H2).total;
 }
 
+int64_t list_query_chunk_rows(size_t workspace_bytes, int64_t n_points, int32_t F, int32_t H1, int32_t H2,
+                              int32_t H3) {
+  (void)H3;
+  if (n_points <= 0 || F <= 0 || H1 <= 0 || H2 <= 0) return 0;
+  return chunk_rows_for(workspace_bytes, n_points, (F + kKTile - 1) / kKTile * kKTile, H1, H2);
+}
+
 int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
   FeatLayout L;
   if (a && a->B >= 0 && a->N >= 0 && (int64_t)a->B * a->N == 0) return LIST_OK;   // empty query: nothing to do
@@ -281,13 +290,19 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
   const int terms = a->precision == LIST_PREC_BF16X3 ? 3 : 1;
   hipStream_t s = (hipStream_t)stream;
 
-  for (int64_t p0 = 0; p0 < P; p0 += rows) {
+  // stage events: one set of LIST_N_STAGES per row chunk (a chunk beyond the caller's sets records nothing);
+  // the gather launcher marks through the same (per-chunk) array
+  ListQueryArgs chunk_args = *a;
+  const int sets = a->stage_events ? (a->stage_event_sets > 0 ? a->stage_event_sets : 1) : 0;
+  int chunk = 0;
+  for (int64_t p0 = 0; p0 < P; p0 += rows, ++chunk) {
     const int n_valid = (int)((P - p0 < rows) ? (P - p0) : rows);
     const int crow = (n_valid + kRowTile - 1) / kRowTile * kRowTile;
     GatherParams g = make_gather(a, L, ws, p0, n_valid, crow);
+    void* const* events = chunk < sets ? a->stage_events + (size_t)chunk * LIST_N_STAGES : nullptr;
+    chunk_args.stage_events = events;
     auto mark = [&](int stage) {
-      if (a->stage_events && a->stage_events[stage])
-        (void)hipEventRecord((hipEvent_t)a->stage_events[stage], s);
+      if (events && events[stage]) (void)hipEventRecord((hipEvent_t)events[stage], s);
     };
     mark(LIST_STAGE_BEGIN);
     hipError_t e = hipSuccess;
@@ -304,7 +319,7 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
       }
     }
     mark(LIST_STAGE_SORT);
-    e = launch_gather(g, L, *a, s);
+    e = launch_gather(g, L, chunk_args, s);
     if (e != hipSuccess) return hip_fail(e, "gather launch");
     mark(LIST_STAGE_TAIL);
 
@@ -381,6 +396,7 @@ int list_percep_pool_fwd(const ListPoolArgs* a, void* stream) {
     return fail(LIST_ERR_ARG, "img_dtype=%d img_C=%d", a->img_dtype, a->img_C);
   if ((int64_t)a->map_size * a->map_size * a->img_C >= (int64_t)1 << 31)
     return fail(LIST_ERR_SHAPE, "image map larger than 2^31 elements");
+  if (!(a->clamp_hi >= 0.f)) return fail(LIST_ERR_ARG, "clamp_hi=%g must be >= 0", (double)a->clamp_hi);
   hipError_t e = launch_percep_pool(*a, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "percep_pool launch");
   return LIST_OK;

@@ -27,18 +27,34 @@ __device__ __forceinline__ unsigned short f2bf(float x) {
 __device__ __forceinline__ float bf2f(unsigned short h) {
   return __builtin_bit_cast(float, (unsigned)h << 16);
 }
+// lo plane of x given its hi plane h: bf16(x - h); an infinity has lo = 0 (inf - inf would make hi + lo a NaN)
+__device__ __forceinline__ unsigned short bf_lo(float x, unsigned short h) {
+  const float d = x - bf2f(h);
+  return f2bf(__builtin_isinf(x) ? 0.f : d);
+}
 __device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
   const unsigned short h0 = f2bf(v.x), h1 = f2bf(v.y), h2 = f2bf(v.z), h3 = f2bf(v.w);
-  const unsigned short l0 = f2bf(v.x - bf2f(h0)), l1 = f2bf(v.y - bf2f(h1));
-  const unsigned short l2 = f2bf(v.z - bf2f(h2)), l3 = f2bf(v.w - bf2f(h3));
+  const unsigned short l0 = bf_lo(v.x, h0), l1 = bf_lo(v.y, h1);
+  const unsigned short l2 = bf_lo(v.z, h2), l3 = bf_lo(v.w, h3);
   hi = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
   lo = make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));
 }
 
 // ---- fp16 (single plane) -------------------------------------------------------------------
+// fp32 -> fp16, round-to-nearest-even, magnitudes above 65504 (and +-inf) saturate, NaN stays NaN
+// (v_med3_f32 alone would turn a NaN into -65504: the reference propagates NaNs, so do the stores).
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+__device__ __forceinline__ float sat_h(float x) {
+  const float c = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+  return (x != x) ? x : c;
+}
 __device__ __forceinline__ unsigned short f2h(float x) {
-  x = fminf(fmaxf(x, -65504.f), 65504.f);                   // saturate (NaN passes through)
-  return __builtin_bit_cast(unsigned short, (_Float16)x);   // v_cvt_f16_f32, RNE
+  return __builtin_bit_cast(unsigned short, (_Float16)sat_h(x));   // v_cvt_f16_f32, RNE
+}
+__device__ __forceinline__ unsigned f2h2(float a, float b) {       // v_cvt_pk_f16_f32: a -> low half
+  const f32x2_t v = {sat_h(a), sat_h(b)};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
 }
 __device__ __forceinline__ float h2f(unsigned short h) {
   return (float)__builtin_bit_cast(_Float16, h);
@@ -48,9 +64,15 @@ __device__ __forceinline__ void put_map(void* out, int64_t i, float v, int f16) 
   else ((float*)out)[i] = v;
 }
 __device__ __forceinline__ uint2 half4(const float4& v) {
+#ifdef LIST_HALF4_SCALAR        // A/B: four scalar conversions + shifts instead of two v_cvt_pk_f16_f32
   return make_uint2((unsigned)f2h(v.x) | ((unsigned)f2h(v.y) << 16),
                     (unsigned)f2h(v.z) | ((unsigned)f2h(v.w) << 16));
+#else
+  return make_uint2(f2h2(v.x, v.y), f2h2(v.z, v.w));
+#endif
 }
+// ReLU as torch computes it: a NaN stays a NaN (v_max_f32 would return 0)
+__device__ __forceinline__ float relu_nan(float x) { return x < 0.f ? 0.f : x; }
 enum { FMT_BF16_SPLIT = 0, FMT_FP16 = 1 };     // element format of X / H / packed weights
 
 // store 4 consecutive features of one row
@@ -78,7 +100,7 @@ __device__ __forceinline__ void store_feat1(unsigned short* x_hi, unsigned short
   } else {
     const unsigned short h = f2bf(v);
     x_hi[off] = h;
-    x_lo[off] = f2bf(v - bf2f(h));
+    x_lo[off] = bf_lo(v, h);
   }
 }
 
@@ -255,12 +277,13 @@ struct Workspace {
   size_t x_hi, x_lo, h1_hi, h1_lo, h2_hi, h2_lo;     // byte offsets
   size_t order, keys, bins;                          // point sort: int32 [rows], [rows], [kSortBins]
   size_t order_img, row_of, keys2;                   // pixel order for the 2-D gather; point -> X row
+  size_t nan_flags;                                  // int32 [rows / 64]
   size_t total;
 };
 inline size_t workspace_row_bytes(int Kp, int H1, int H2) {
-  return (size_t)2 * 2 * ((size_t)Kp + H1 + H2) + 20;
+  return (size_t)2 * 2 * ((size_t)Kp + H1 + H2) + 21;
 }
-inline size_t workspace_fixed_bytes() { return (size_t)kSortBins * 4 + 16 * 256; }
+inline size_t workspace_fixed_bytes() { return (size_t)kSortBins * 4 + 17 * 256; }
 inline Workspace workspace_layout(int64_t rows, int Kp, int H1, int H2) {
   Workspace w;
   size_t o = 0;
@@ -272,6 +295,7 @@ inline Workspace workspace_layout(int64_t rows, int Kp, int H1, int H2) {
   w.order_img = take((size_t)rows * 4); w.row_of = take((size_t)rows * 4);
   w.keys2 = take((size_t)rows * 4);
   w.bins = take((size_t)kSortBins * 4);
+  w.nan_flags = take((size_t)(rows / kGatherRows + 1) * 4);
   w.total = o;
   return w;
 }
@@ -290,6 +314,7 @@ struct GatherParams {
   const int* order;           // row -> chunk-local point index (Morton order), or nullptr
   const int* order_img;       // 2-D gather: slot -> chunk-local point index (pixel order), or nullptr
   const int* row_of;          // chunk-local point index -> X row (inverse of `order`)
+  int* nan_flags;             // [rows / 64]: set by a voxel gather whose result holds a NaN (k_gather_fixup)
 };
 
 struct GemmParams {

@@ -26,10 +26,12 @@ __device__ __forceinline__ Pt load_point(const GatherParams& g, int row) {
 // grid_sampler_unnormalize (align_corners) + clip_coordinates + floor, as ATen computes them:
 //   v = ((c + 1) / 2) * (size - 1); v = min(size-1, max(v, 0)); i0 = floor(v)
 //   w1 = v - i0 ; w0 = (i0 + 1) - v ; the +1 tap is skipped when i0 + 1 == size (its weight is 0)
+// A NaN coordinate: ATen's CPU kernel clips with std::min(size-1, std::max(v, 0)), whose comparisons are
+// all false for a NaN, so it comes out as size-1 (pinned by tests/golden/hotpath_edge_nan.npz).
 struct Axis { int i0; int has1; float w0, w1; };
 __device__ __forceinline__ Axis axis_setup(float c, int size) {
   float v = ((c + 1.f) * 0.5f) * (float)(size - 1);
-  v = fminf((float)(size - 1), fmaxf(v, 0.f));
+  v = (v != v) ? (float)(size - 1) : fminf((float)(size - 1), fmaxf(v, 0.f));
   const float f = floorf(v);
   Axis a;
   a.i0 = (int)f;
@@ -41,7 +43,10 @@ __device__ __forceinline__ Axis axis_setup(float c, int size) {
 
 // The 8 taps of one trilinear sample: element offsets (relative to the image/channel base) and
 // weights in the accumulation order of the ATen CPU kernel: tnw tne tsw tse bnw bne bsw bse.
-struct Taps { int o[8]; float w[8]; };
+// `dead`: bit k set = tap k lies beyond the border (index == size) and is SKIPPED by the reference; the fast
+// paths read the border voxel instead and multiply by its exactly-zero weight, which is the same number unless
+// that voxel holds +-inf / NaN -- the gathers detect a NaN result and re-reduce with reduce_taps_exact.
+struct Taps { int o[8]; float w[8]; int dead; };
 
 __device__ __forceinline__ Taps make_taps(float x, float y, float z, int C, int D, int H, int W) {
   const Axis ax = axis_setup(x, W), ay = axis_setup(y, H), az = axis_setup(z, D);
@@ -58,6 +63,7 @@ __device__ __forceinline__ Taps make_taps(float x, float y, float z, int C, int 
   t.w[2] = ax.w0 * ay.w1 * az.w0; t.w[3] = ax.w1 * ay.w1 * az.w0;
   t.w[4] = ax.w0 * ay.w0 * az.w1; t.w[5] = ax.w1 * ay.w0 * az.w1;
   t.w[6] = ax.w0 * ay.w1 * az.w1; t.w[7] = ax.w1 * ay.w1 * az.w1;
+  t.dead = (ax.has1 ? 0 : 0xAA) | (ay.has1 ? 0 : 0xCC) | (az.has1 ? 0 : 0xF0);
   return t;
 }
 
@@ -72,7 +78,8 @@ __device__ __forceinline__ void stencil_point(const Pt& p, float& x, float& y, f
 // ---- 2-D perceptual pooling ---------------------------------------------------------------------
 // network/modules.py:37-47 per point.  torch.matmul evaluates the K=4 dot product as an fma chain
 // in k order (oracle/list_oracle.py project_points, checked bit-for-bit).
-struct Proj { int o00, o01, o10, o11; float w00, w01, w10, w11; };
+// `dead`: bit 0..3 set = tap 00 / 01 / 10 / 11 is outside the map (zeros padding: the reference adds nothing)
+struct Proj { int o00, o01, o10, o11; float w00, w01, w10, w11; int dead; };
 
 __device__ __forceinline__ float clamp_keep_nan(float v, float hi) {
   return (v != v) ? v : fminf(fmaxf(v, 0.f), hi);
@@ -97,9 +104,21 @@ __device__ __forceinline__ Proj project(const float* __restrict__ T, float px, f
   const int x0 = min(max((int)fx, 0), ms - 1), y0 = min(max((int)fy, 0), ms - 1);
   const int x1 = min(x0 + 1, ms - 1), y1 = min(y0 + 1, ms - 1);
   Proj r;
+  // in-bounds tests of the reference on the UNCLAMPED indices.  With clamp_hi <= ms-1 (the reference's 136 on
+  // its 137^2 map) only the +1 taps at ix == ms-1 / iy == ms-1 fall outside, with weight 0; a smaller map under
+  // the hard-coded clamp (modules.py:43 with map_size < 137) puts whole samples outside: zeros padding
+  const bool x1_out = !(fx + 1.f <= (float)(ms - 1)), y1_out = !(fy + 1.f <= (float)(ms - 1));
+  const bool x0_out = !(fx >= 0.f && fx <= (float)(ms - 1)), y0_out = !(fy >= 0.f && fy <= (float)(ms - 1));
+  r.dead = ((x0_out || y0_out) ? 1 : 0) | ((x1_out || y0_out) ? 2 : 0) | ((x0_out || y1_out) ? 4 : 0) |
+           ((x1_out || y1_out) ? 8 : 0);
   r.o00 = (y0 * ms + x0) * Ct; r.o01 = (y0 * ms + x1) * Ct;
   r.o10 = (y1 * ms + x0) * Ct; r.o11 = (y1 * ms + x1) * Ct;
   r.w00 = wx0 * wy0; r.w01 = wx1 * wy0; r.w10 = wx0 * wy1; r.w11 = wx1 * wy1;
+  // an out-of-map tap contributes 0 * weight in the reference: nothing, unless the weight is NaN (NaN coordinates)
+  if ((r.dead & 1) && r.w00 == r.w00) r.w00 = 0.f;
+  if ((r.dead & 2) && r.w01 == r.w01) r.w01 = 0.f;
+  if ((r.dead & 4) && r.w10 == r.w10) r.w10 = 0.f;
+  if ((r.dead & 8) && r.w11 == r.w11) r.w11 = 0.f;
   return r;
 }
 

@@ -237,9 +237,145 @@ static bool try_prep_img_nhwc(const ListMap2D& m, int B, int ms, int Ct, int cof
   return true;
 }
 
+// Row-streaming resize, all levels in ONE launch (C % 64 == 0 levels; any strides).
+// The bilinear form of ATen is separable in exactly the order it is evaluated:
+//   out = (v00 wx0 + v01 wx1) wy0 + (v10 wx0 + v11 wx1) wy1 = top(y0) wy0 + bot(y1) wy1,
+// so a thread that owns (output column x, 8 channels) and walks down RY output rows keeps the two
+// horizontally interpolated source rows in registers and only fetches a new one when y0 advances:
+// on the up-sampled levels (14/28/56 px -> 137: 87 % of the output bytes) that is one fetch per 10 / 5 /
+// 2.5 output rows and 3 flops per output element instead of 7 (the tile kernel above spends more issue
+// slots on arithmetic and index math than the 16-B store it feeds can hide).  No LDS: the 8 lanes of a
+// pixel read 8-channel groups of the same two taps (L1/L2 hits), and write one full 128-B line (fp16:
+// 64 channels; fp32: 256 B) per pixel, 8 pixels per wave-instruction.  Same bits as k_prep_img.
+constexpr int kRowsPx = 16;                 // output columns per workgroup (x 8 channel octets = 128 threads)
+constexpr int kRowsCg = 64;                 // channels per workgroup
+struct PrepRowsLevel { ListMap2D m; int coff, wg_begin, cgroups, vec; };
+struct PrepRowsArgs { PrepRowsLevel lv[LIST_N_IMG_LEVELS]; int n_levels, B, ms, Ct, nxt, nyt, RY; };
+
+template <int F16>
+__global__ __launch_bounds__(128) void k_prep_img_rows(PrepRowsArgs a, void* __restrict__ out) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < LIST_N_IMG_LEVELS; ++i)
+    if (i < a.n_levels && (int)blockIdx.x >= a.lv[i].wg_begin) l = i;
+  const ListMap2D m = a.lv[l].m;
+  const int coff = a.lv[l].coff, cgroups = a.lv[l].cgroups, vec = a.lv[l].vec;
+  int idx = blockIdx.x - a.lv[l].wg_begin;
+  const int xt = idx % a.nxt; idx /= a.nxt;
+  const int cg = idx % cgroups; idx /= cgroups;
+  const int yt = idx % a.nyt;
+  const int b = idx / a.nyt;
+  const int ms = a.ms;
+  const int q = threadIdx.x & 7, xi = threadIdx.x >> 3;
+  const int xo = xt * kRowsPx + xi;
+  const bool active = xo < ms;
+  const int x = active ? xo : ms - 1;
+  const int c = cg * kRowsCg + 8 * q;
+
+  const float sy = ms > 1 ? (float)(m.H - 1) / (float)(ms - 1) : 0.f;
+  const float sx = ms > 1 ? (float)(m.W - 1) / (float)(ms - 1) : 0.f;
+  const float fx = sx * (float)x;
+  const int x0 = min((int)fx, m.W - 1);
+  const int x1 = x0 + (x0 < m.W - 1 ? 1 : 0);
+  const float wx1 = fx - (float)x0, wx0 = 1.f - wx1;
+  const float* p0 = m.data + (int64_t)b * m.sb + (int64_t)c * m.sc + (int64_t)x0 * m.sw;
+  const float* p1 = m.data + (int64_t)b * m.sb + (int64_t)c * m.sc + (int64_t)x1 * m.sw;
+
+  auto hrow = [&](int r, float (&h)[8]) {
+    const float* r0 = p0 + (int64_t)r * m.sh;
+    const float* r1 = p1 + (int64_t)r * m.sh;
+    float u[8], v[8];
+    if (vec) {                      // channels-last source: 8 channels are 32 contiguous bytes
+      const float4 a0 = *(const float4*)r0, a1 = *(const float4*)(r0 + 4);
+      const float4 b0 = *(const float4*)r1, b1 = *(const float4*)(r1 + 4);
+      u[0] = a0.x; u[1] = a0.y; u[2] = a0.z; u[3] = a0.w; u[4] = a1.x; u[5] = a1.y; u[6] = a1.z; u[7] = a1.w;
+      v[0] = b0.x; v[1] = b0.y; v[2] = b0.z; v[3] = b0.w; v[4] = b1.x; v[5] = b1.y; v[6] = b1.z; v[7] = b1.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { u[k] = r0[(int64_t)k * m.sc]; v[k] = r1[(int64_t)k * m.sc]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) h[k] = u[k] * wx0 + v[k] * wx1;
+  };
+
+  const int y_first = yt * a.RY, y_end = min(y_first + a.RY, ms);
+  float top[8], bot[8];
+  int row_top = -1, row_bot = -1;
+  int64_t oi = ((int64_t)(b * ms + y_first) * ms + xo) * a.Ct + coff + c;
+  const int64_t ostep = (int64_t)ms * a.Ct;
+#pragma unroll 1
+  for (int y = y_first; y < y_end; ++y, oi += ostep) {
+    const float fy = sy * (float)y;
+    const int y0 = min((int)fy, m.H - 1);
+    const int y1 = y0 + (y0 < m.H - 1 ? 1 : 0);
+    const float wy1 = fy - (float)y0, wy0 = 1.f - wy1;
+    if (y0 != row_top) {                       // (wave-uniform branches: y is the same for the workgroup)
+      if (y0 == row_bot) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) top[k] = bot[k];
+      } else {
+        hrow(y0, top);
+      }
+      row_top = y0;
+    }
+    if (y1 != row_bot) {
+      if (y1 == row_top) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bot[k] = top[k];
+      } else {
+        hrow(y1, bot);
+      }
+      row_bot = y1;
+    }
+    float o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = top[k] * wy0 + bot[k] * wy1;
+    if (!active) continue;
+    if (F16) {
+      const uint2 lo = half4(make_float4(o[0], o[1], o[2], o[3]));
+      const uint2 hi = half4(make_float4(o[4], o[5], o[6], o[7]));
+      *(uint4*)((unsigned short*)out + oi) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    } else {
+      *(float4*)((float*)out + oi) = make_float4(o[0], o[1], o[2], o[3]);
+      *(float4*)((float*)out + oi + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+  }
+}
+
+static bool rows_eligible(const ListMap2D& m, int ms, int Ct, int coff) {
+  return ms >= 2 && m.C >= kRowsCg && (m.C % kRowsCg) == 0 && (coff % 8) == 0 && (Ct % 8) == 0;
+}
+
 hipError_t launch_prep_img(const ListMap2D maps[LIST_N_IMG_LEVELS], int B, int map_size, int Ct,
                            int f16, void* out, hipStream_t s) {
   int coff = 0;
+#ifndef LIST_PREP_IMG_NO_ROWS
+  {
+    PrepRowsArgs a;
+    a.n_levels = 0; a.B = B; a.ms = map_size; a.Ct = Ct; a.RY = 16;
+    a.nxt = (map_size + kRowsPx - 1) / kRowsPx; a.nyt = (map_size + a.RY - 1) / a.RY;
+    int64_t wgs = 0;
+    bool all = true;
+    int co = 0;
+    for (int i = 0; i < LIST_N_IMG_LEVELS; ++i) {
+      const ListMap2D& m = maps[i];
+      if (!rows_eligible(m, map_size, Ct, co)) { all = false; break; }
+      PrepRowsLevel& lv = a.lv[a.n_levels++];
+      lv.m = m; lv.coff = co; lv.wg_begin = (int)wgs; lv.cgroups = m.C / kRowsCg;
+      lv.vec = (m.sc == 1 && (m.sw % 4) == 0 && (m.sh % 4) == 0 && (m.sb % 4) == 0 &&
+                (reinterpret_cast<uintptr_t>(m.data) & 15) == 0) ? 1 : 0;
+      wgs += (int64_t)B * a.nyt * lv.cgroups * a.nxt;
+      co += m.C;
+    }
+    if (all && wgs > 0 && wgs < 2147483647LL) {
+      if (f16)
+        hipLaunchKernelGGL(k_prep_img_rows<1>, dim3((unsigned)wgs), dim3(128), 0, s, a, out);
+      else
+        hipLaunchKernelGGL(k_prep_img_rows<0>, dim3((unsigned)wgs), dim3(128), 0, s, a, out);
+      return hipGetLastError();
+    }
+  }
+#endif
   for (int i = 0; i < LIST_N_IMG_LEVELS; ++i) {
     const ListMap2D& m = maps[i];
     hipError_t fe = hipSuccess;
@@ -402,7 +538,7 @@ __global__ __launch_bounds__(256) void k_prep_w0(const float* __restrict__ w0, F
   if (fmt == FMT_FP16) { hi[i] = f2h(v); return; }
   const unsigned short h = f2bf(v);
   hi[i] = h;
-  lo[i] = f2bf(v - bf2f(h));
+  lo[i] = bf_lo(v, h);
 }
 
 __global__ __launch_bounds__(256) void k_split(const float4* __restrict__ x, uint2* __restrict__ hi,

@@ -69,7 +69,8 @@ class ListQueryArgs(C.Structure):
                 ("sdf", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("precision", C.c_int32),
-                ("stage_events", C.POINTER(C.c_void_p)), ("no_sort", C.c_int32)]
+                ("stage_events", C.POINTER(C.c_void_p)), ("no_sort", C.c_int32),
+                ("stage_event_sets", C.c_int32)]
 
 
 class ListMlpGrads(C.Structure):
@@ -127,6 +128,7 @@ EXPORTS = {
                                         C.c_void_p]),
     "list_query_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                                 C.c_int32]),
+    "list_query_chunk_rows": (C.c_int64, [C.c_size_t, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "list_sdf_query_fwd": (C.c_int, [C.POINTER(ListQueryArgs), C.c_void_p]),
     "list_percep_pool_fwd": (C.c_int, [C.POINTER(ListPoolArgs), C.c_void_p]),
     "list_gather_features_fwd": (C.c_int, [C.POINTER(ListQueryArgs), C.c_void_p, C.c_void_p]),
@@ -391,6 +393,16 @@ def _fill_query_args(query, perm, scale, vox, packed, precision, trans_mat=None,
     return a, keep
 
 
+def query_chunks(n_points, packed):
+    """Row chunks list_sdf_query_fwd cuts a query of n_points into (with the workspace sdf_query gives it)."""
+    lib = load()
+    nbytes = lib.list_query_workspace_bytes(n_points, packed.F, packed.H1, packed.H2, packed.H3)
+    rows = lib.list_query_chunk_rows(nbytes, n_points, packed.F, packed.H1, packed.H2, packed.H3)
+    if rows <= 0:
+        raise RuntimeError("list_query_chunk_rows failed")
+    return (n_points + rows - 1) // rows
+
+
 class QueryContext:
     """What list_sdf_query_bwd needs from a forward call: its argument block (pointers into tensors
     kept alive here) including the private workspace."""
@@ -404,7 +416,8 @@ def sdf_query(query, trans_mat, img, vox, packed, perm=(2, 1, 0), scale=2.0, pre
               save_for_backward=False):
     """The fused hot path, network/models.py:91-97 -> sdf [B,N] (float32).
 
-    stage_events: optional ctypes array (c_void_p * N_STAGES) of hipEvent_t handles.
+    stage_events: optional ctypes array (c_void_p * (n * N_STAGES)) of hipEvent_t handles, one set of N_STAGES
+    per row chunk (query_chunks() says how many chunks a query of B*N points takes).
     save_for_backward: return (sdf, QueryContext) for sdf_query_backward."""
     lib = load()
     if query.dim() == 3 and query.shape[0] * query.shape[1] == 0:      # empty query -> empty field
@@ -416,6 +429,7 @@ def sdf_query(query, trans_mat, img, vox, packed, perm=(2, 1, 0), scale=2.0, pre
     a.no_sort = 0 if sort_points else 1
     if stage_events is not None:
         a.stage_events = C.cast(stage_events, C.POINTER(C.c_void_p))
+        a.stage_event_sets = max(1, len(stage_events) // N_STAGES)
     B, N = a.B, a.N
     sdf = out if out is not None else torch.empty((B, N), dtype=torch.float32, device=query.device)
     if not sdf.is_contiguous() or sdf.dtype != torch.float32 or tuple(sdf.shape) != (B, N):

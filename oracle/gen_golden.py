@@ -53,7 +53,10 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     pool = M.PerceptualPooling()
 
-    for name in cases.CASE_NAMES:
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--case=")]
+    for name in cases.CASE_NAMES + cases.NONFINITE_CASE_NAMES:
+        if only and name not in only:
+            continue
         c = cases.build_case(name)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
         dec.load_state_dict({"fc." + k: t(v) for k, v in c["weights"].items()})
@@ -78,7 +81,7 @@ def main():
             vf = vf.reshape(B, vf.shape[1] * vf.shape[3], vf.shape[4])  # [B,2583,N]
             resized0 = torch.nn.functional.interpolate(img_maps[0], size=137, mode="bilinear",
                                                        align_corners=True)
-        sub = slice(0, None, 4)
+        sub = slice(0, None, cases.FEATURE_STRIDE.get(name, 4))
         np.savez_compressed(
             os.path.join(OUT, f"hotpath_{name}.npz"),
             sdf=sdf.numpy(),
@@ -87,7 +90,10 @@ def main():
             resized0_sub=resized0.numpy()[:, ::8, ::3, ::3],
             torch_version=np.array(torch.__version__),
         )
-        print(name, "sdf", tuple(sdf.shape), float(sdf.abs().max()))
+        print(name, "sdf", tuple(sdf.shape), float(torch.nan_to_num(sdf, 0.0, 0.0, 0.0).abs().max()),
+              "non-finite:", int((~torch.isfinite(sdf)).sum()))
+    if only:
+        return
 
     # a6: grid builder; losses
     grid = U.create_grid_points_from_bounds(-0.5, 0.5, 8)

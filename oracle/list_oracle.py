@@ -142,7 +142,10 @@ def grid_sample_3d_border(f, p):
 
     def unnorm(c, size):
         v = (((c + F32(1)) / F32(2)) * F32(size - 1)).astype(F32)
-        return np.minimum(F32(size - 1), np.maximum(v, F32(0))).astype(F32)
+        # ATen's CPU clip_coordinates is std::min(size-1, std::max(v, 0)): every comparison with a NaN is
+        # false, so a NaN coordinate comes out as size-1 (pinned by tests/golden/hotpath_edge_nan.npz)
+        clipped = np.minimum(F32(size - 1), np.maximum(v, F32(0))).astype(F32)
+        return np.where(np.isnan(v), F32(size - 1), clipped).astype(F32)
 
     ix, iy, iz = unnorm(p[..., 0], W), unnorm(p[..., 1], H), unnorm(p[..., 2], D)
     x0f, y0f, z0f = np.floor(ix), np.floor(iy), np.floor(iz)

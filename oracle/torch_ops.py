@@ -16,11 +16,12 @@ _STENCIL = torch.tensor([[0, 0, 0], [-1, 0, 0], [1, 0, 0], [0, -1, 0], [0, 1, 0]
                          [0, 0, -1], [0, 0, 1]], dtype=torch.float32) * 0.0722
 
 
-def pooled_image_features(img_maps, pts, trans_mat, map_size=137):
-    """modules.py:24-54 -> [B,1024,N]."""
+def pooled_image_features(img_maps, pts, trans_mat, map_size=137, clamp_hi=136.0):
+    """modules.py:24-54 -> [B,1024,N].  clamp_hi: the reference hard-codes 136 (modules.py:43); BASELINE config 5
+    (map 274^2) clamps at map_size-1 instead."""
     ones = pts.new_ones(pts.shape[0], pts.shape[1], 1)
     cam = torch.matmul(torch.cat((pts, ones), dim=-1), trans_mat)
-    uv = (cam[..., :2] / (cam[..., 2:] + 1e-8)).clamp(0.0, 136.0)
+    uv = (cam[..., :2] / (cam[..., 2:] + 1e-8)).clamp(0.0, clamp_hi)
     half = (map_size - 1) / 2.0
     grid = ((uv - half) / half).unsqueeze(1)
     sampled = []
@@ -49,16 +50,16 @@ def implicit_mlp(features, weights):
 
 
 @torch.no_grad()
-def list_query(query, img_maps, vox_maps, trans_mat, weights, pre_permuted=False):
+def list_query(query, img_maps, vox_maps, trans_mat, weights, pre_permuted=False, map_size=137, clamp_hi=136.0):
     """models.py:91-97 -> sdf [B,N]."""
     pts = query if pre_permuted else query[:, :, [2, 1, 0]] * 2
-    percep = pooled_image_features(img_maps, pts, trans_mat)
+    percep = pooled_image_features(img_maps, pts, trans_mat, map_size, clamp_hi)
     feats = torch.cat((stencil_voxel_features(pts, vox_maps), percep, pts.transpose(1, 2)), dim=1)
     return implicit_mlp(feats, weights)
 
 
 def list_query_grads(query, img_maps, vox_maps, trans_mat, weights, grad_sdf, pre_permuted=False,
-                     map_size=137):
+                     map_size=137, clamp_hi=136.0):
     """Backward of the path by autograd over the same op sequence (the reference trains through
     exactly these ops, train.py:82-85): gradients of sum(sdf * grad_sdf) w.r.t. the 2-D maps, the 3-D
     maps, trans_mat and the MLP parameters.  Returns (sdf, dict)."""
@@ -69,7 +70,7 @@ def list_query_grads(query, img_maps, vox_maps, trans_mat, weights, grad_sdf, pr
         T = leaf(trans_mat)
         W = {k: leaf(v) for k, v in weights.items()}
         pts = query if pre_permuted else query[:, :, [2, 1, 0]] * 2
-        percep = pooled_image_features(img_l, pts, T, map_size)
+        percep = pooled_image_features(img_l, pts, T, map_size, clamp_hi)
         feats = torch.cat((stencil_voxel_features(pts, vox_l), percep, pts.transpose(1, 2)), dim=1)
         sdf = implicit_mlp(feats, W)
         (sdf * grad_sdf).sum().backward()

@@ -36,11 +36,19 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_error_string_without_gpu():
     from list_amd import hip
     lib = hip.load()
-    assert lib.list_abi_version() == 3
+    assert lib.list_abi_version() == 4
+    text = open(os.path.join(ROOT, "include", "list_hip.h")).read()
+    assert "#define LIST_ABI_VERSION 4" in text
     # argument validation happens before any HIP call: a NULL args struct is rejected cleanly
     assert lib.list_sdf_query_fwd(None, None) == -1
     assert b"NULL" in lib.list_last_error()
-    assert lib.list_query_workspace_bytes(160000, 3610, 512, 256, 256) > 2 * 160000 * 3648 * 2
+    ws = lib.list_query_workspace_bytes(160000, 3610, 512, 256, 256)
+    assert ws > 2 * 160000 * 3648 * 2
+    # host-side chunk arithmetic: the metric shape is one chunk, a 256^3 grid is 64 chunks of 262144 rows
+    assert lib.list_query_chunk_rows(ws, 160000, 3610, 512, 256, 256) == 160000
+    big = lib.list_query_workspace_bytes(256 ** 3, 3610, 512, 256, 256)
+    assert lib.list_query_chunk_rows(big, 256 ** 3, 3610, 512, 256, 256) == 262144
+    assert lib.list_query_chunk_rows(1 << 20, 256 ** 3, 3610, 512, 256, 256) == 0
 
 
 def test_missing_library_fails_loudly(monkeypatch):

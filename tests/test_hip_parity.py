@@ -310,10 +310,53 @@ def test_fused_sdf_matches_reference(hip, golden_dir, name):
         hip.sdf_query(dev(c["query"]), dev(c["trans_mat"]), img, vox, packed, precision="fp16")
 
 
+@pytest.mark.parametrize("name", cases.NONFINITE_CASE_NAMES)
+def test_non_finite_inputs_follow_the_reference(hip, golden_dir, name):
+    """NaN query coordinates, a 0/0 projection, +-inf / NaN voxels and pixels (at taps the reference skips, inside
+    the shared-tap windows with weight 0, and at taps it uses): the gathered features and the SDF agree with the
+    reference's own outputs (tests/golden/hotpath_edge_nan.npz) INCLUDING the positions of every NaN and the
+    positions and signs of every infinity.  Reference: network/modules.py:42-52,263-265 through ATen's CPU
+    grid_sample (clip_coordinates turns a NaN into size-1; a border tap at index == size is skipped; zeros padding
+    multiplies a 0 by the weight)."""
+    g = golden(golden_dir, name)
+    c = cases.build_case(name)
+    st = cases.FEATURE_STRIDE[name]
+    q = dev(O.permute_scale_query(c["query"]))
+    B, N = q.shape[:2]
+    # fp32-grade path: IEEE propagation end to end
+    img, vox, packed = prepare(hip, c)
+    feats = hip.gather_features(dev(c["query"]), dev(c["trans_mat"]), img, vox, packed).cpu().numpy()
+    ref_v, ref_p = g["voxfeat_sub"], g["percep_sub"][:, :, 0, :]
+    got_v, got_p = feats[:, :2583, ::st], feats[:, 2583:2583 + 1024, ::st]
+    for got, ref, what in ((got_v, ref_v, "voxel"), (got_p, ref_p, "perceptual")):
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(ref), err_msg=what + ": NaN positions")
+        np.testing.assert_array_equal(np.isposinf(got), np.isposinf(ref), err_msg=what + ": +inf positions")
+        np.testing.assert_array_equal(np.isneginf(got), np.isneginf(ref), err_msg=what + ": -inf positions")
+        fin = np.isfinite(ref)
+        assert np.abs(got[fin] - ref[fin]).max() < 2e-5 + 4 * 2.0 ** -15, what
+    pooled = hip.percep_pool(q, dev(c["trans_mat"]), img).cpu().numpy()[:, :, 0, ::st]
+    np.testing.assert_allclose(pooled, ref_p, rtol=0, atol=2e-5)          # (NaN == NaN, inf == inf)
+    sdf = hip.sdf_query(dev(c["query"]), dev(c["trans_mat"]), img, vox, packed).cpu().numpy()
+    np.testing.assert_allclose(sdf, g["sdf"], rtol=0, atol=TOL_X3)
+    assert np.isnan(g["sdf"]).sum() >= 8 and np.isfinite(g["sdf"]).sum() >= 8
+    # fp16 path: a NaN stays a NaN everywhere (stores, ReLU); infinities SATURATE to +-65504 by design, so a
+    # row that the reference makes non-finite only through an infinity may come out finite -- never the reverse
+    img16, vox16, packed16 = prepare(hip, c, "fp16")
+    sdf16 = hip.sdf_query(dev(c["query"]), dev(c["trans_mat"]), img16, vox16, packed16, precision="fp16").cpu().numpy()
+    fin = np.isfinite(g["sdf"])
+    assert np.isfinite(sdf16[fin]).all() and np.abs(sdf16[fin] - g["sdf"][fin]).max() < TOL_FP16
+    nan_coord = np.isnan(c["query"]).any(-1)
+    assert np.isnan(sdf16[nan_coord]).all()
+
+
 def test_fp16_saturates_instead_of_overflowing(hip):
     x = torch.tensor([1e6, -1e6, 65504.0, 1.0], device="cuda:0")
     h = hip.to_fp16(x).view(torch.float16).float().cpu().numpy()
     np.testing.assert_array_equal(h, [65504.0, -65504.0, 65504.0, 1.0])
+    y = torch.tensor([float("nan"), float("inf"), -float("inf"), 2.0], device="cuda:0")
+    h = hip.to_fp16(y).view(torch.float16).float().cpu().numpy()
+    assert np.isnan(h[0])                                    # a NaN is not an overflow: it stays a NaN
+    np.testing.assert_array_equal(h[1:], [65504.0, -65504.0, 2.0])
 
 
 def test_module_level_path_equals_fused(hip, golden_dir):
