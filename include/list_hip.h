@@ -182,9 +182,12 @@ enum ListStage {
   LIST_STAGE_IMG = 7,     /* k_gather_img: projection + bilinear sample  (modules.py:37-52) */
   LIST_STAGE_TAIL = 8,    /* k_gather_tail: C == 1 level, xyz, padding   (modules.py:257) */
   LIST_STAGE_FC0 = 9,     /* k_gemm_nt: fc_0 + ReLU                       (modules.py:276) */
-  LIST_STAGE_FC1 = 10,    /* k_gemm_nt: fc_1 + ReLU                       (modules.py:277) */
-  LIST_STAGE_FC2 = 11,    /* k_gemm_nt: fc_2 + ReLU + fc_out -> sdf       (modules.py:278-281) */
-  LIST_N_STAGES = 12
+  LIST_STAGE_EXACT = 10,  /* k_gather_fixup + gated fc_0: exact redo of the row tiles whose fc_0 output holds */
+                          /*   a NaN (reference skip semantics for +-inf / NaN map values at border taps);   */
+                          /*   both launches exit at once on finite inputs                                   */
+  LIST_STAGE_FC1 = 11,    /* k_gemm_nt: fc_1 + ReLU                       (modules.py:277) */
+  LIST_STAGE_FC2 = 12,    /* k_gemm_nt: fc_2 + ReLU + fc_out -> sdf       (modules.py:278-281) */
+  LIST_N_STAGES = 13
 };
 
 size_t list_query_workspace_bytes(int64_t n_points, int32_t F, int32_t H1, int32_t H2, int32_t H3);

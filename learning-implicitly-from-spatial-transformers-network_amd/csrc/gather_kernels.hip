@@ -57,11 +57,12 @@ __device__ __forceinline__ void tap_fma(const typename M::Raw& r, float w, float
 // ---- exact border semantics (cold path) -----------------------------------------------------------------
 // The fast reductions multiply a tap the reference SKIPS (index == size under border padding, outside the map
 // under zeros padding) by its exactly-zero weight.  That is the same number unless the voxel read in its place
-// holds +-inf or NaN (0 * inf = NaN where the reference adds nothing).  Every gather therefore probes its result
-// for NaN.  The voxel gathers flag the 64-row group of such a row (GatherParams.nan_flags) and k_gather_fixup,
-// launched behind them, redoes flagged groups with the skipped taps' VALUES forced to zero; the 2-D gather and
-// the scalar tail re-reduce in place.  None of this runs on finite maps (one predicated store and one
-// 1-workgroup-per-64-rows launch that reads a flag and exits).
+// holds +-inf or NaN (0 * inf = NaN where the reference adds nothing).  Such a NaN reaches every column of the
+// row's fc_0 output, so fc_0's epilogue probes for NaN per 256-row tile (GemmParams.nan_tiles), k_gather_fixup
+// redoes the gathers of flagged tiles with the skipped taps' VALUES forced to zero, and fc_0 runs again gated on
+// the same flags (list_capi.hip).  On finite inputs the two gated launches exit at their first instruction; the
+// gather kernels themselves carry no probe (one in them cost 40-90 %: it splits the tap loads into dependent
+// batches).  The scalar tail re-reduces in place (one sample per lane, no measurable cost).
 template <int V>
 __device__ __forceinline__ bool any_nan(const float (&a)[V]) {
   bool bad = false;
@@ -95,10 +96,18 @@ __device__ __forceinline__ void reduce_taps_exact(const typename M::Raw (&v)[8],
   for (int k = 0; k < 8; ++k) tap_fma_masked<M>(v[k], t.w[k], (t.dead >> k) & 1, acc);   // (tap 0 is never skipped)
 }
 
-// store V consecutive features of one row of X
+// store V consecutive features of one row of X.  V == 8 means the values were interpolated from fp16 maps and
+// cannot leave the fp16 range: no saturation step (half4_inrange)
 template <int FMT, int V>
 __device__ __forceinline__ void store_feats(unsigned short* __restrict__ xh, unsigned short* __restrict__ xl,
                                             int64_t off, const float (&a)[V], bool valid) {
+  if constexpr (FMT == FMT_FP16 && V == 8) {       // 8 halfs: one 16-B store
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    const uint2 lo = half4_inrange(valid ? make_float4(a[0], a[1], a[2], a[3]) : make_float4(0.f, 0.f, 0.f, 0.f));
+    const uint2 hi = half4_inrange(valid ? make_float4(a[4], a[5], a[6], a[7]) : make_float4(0.f, 0.f, 0.f, 0.f));
+    __builtin_nontemporal_store((u32x4){lo.x, lo.y, hi.x, hi.y}, (u32x4*)(xh + off));
+    return;
+  }
 #pragma unroll
   for (int h = 0; h < V / 4; ++h) {
     float4 v = valid ? make_float4(a[4 * h], a[4 * h + 1], a[4 * h + 2], a[4 * h + 3])
@@ -117,7 +126,7 @@ __device__ __forceinline__ void reduce_taps(const typename M::Raw (&v)[8], const
 // Two stencil points at a time: all 16 tap loads are issued before the first use, so a wave has
 // 16 KB in flight per step instead of one dependent 8-load round trip per stencil point.
 template <int C, int J0, int J1, int FMT, typename M>
-__device__ __forceinline__ bool gather_pair(const ListVoxLevel& lv, const void* __restrict__ base,
+__device__ __forceinline__ void gather_pair(const ListVoxLevel& lv, const void* __restrict__ base,
                                             int64_t boff, const Pt& p, unsigned short* __restrict__ xh,
                                             unsigned short* __restrict__ xl, int64_t out_off) {
   float x0, y0, z0, x1, y1, z1;
@@ -134,14 +143,11 @@ __device__ __forceinline__ bool gather_pair(const ListVoxLevel& lv, const void* 
   }
   float r[M::V];
   reduce_taps<M>(v0, t0, r);
-  bool bad = any_nan<M::V>(r);
   store_feats<FMT, M::V>(xh, xl, out_off + J0 * C, r, p.valid);
   if (J1 != J0) {
     reduce_taps<M>(v1, t1, r);
-    bad = bad || any_nan<M::V>(r);
     store_feats<FMT, M::V>(xh, xl, out_off + J1 * C, r, p.valid);
   }
-  return bad;
 }
 
 // grid = rows/RB, block = 256.  LP = C/V lanes share a point; a wave covers 64/LP points.  The
@@ -154,8 +160,11 @@ template <int C, int V> struct VoxGeom {
   static constexpr int RB = 4 * PW * ITERS;                         // rows per workgroup: 64, 128 or 256
 };
 
+#ifndef LIST_VOX_WAVES
+#define LIST_VOX_WAVES 1
+#endif
 template <int C, int FMT, int F16>
-__global__ __launch_bounds__(256) void k_gather_vox(GatherParams g, ListVoxLevel lv, int col_off) {
+__global__ __launch_bounds__(256, LIST_VOX_WAVES) void k_gather_vox(GatherParams g, ListVoxLevel lv, int col_off) {
   using M = MapT<F16>;
   using G = VoxGeom<C, M::V>;
   __shared__ Pt pts[G::RB];
@@ -173,11 +182,10 @@ __global__ __launch_bounds__(256) void k_gather_vox(GatherParams g, ListVoxLevel
     const Pt p = pts[local];
     const int64_t boff = (int64_t)p.b * lv.image_stride + sub * M::V;
     const int64_t out_off = (int64_t)row * g.Kp + col_off + sub * M::V;
-    bool bad = gather_pair<C, 0, 1, FMT, M>(lv, lv.data, boff, p, xh, xl, out_off);
-    bad |= gather_pair<C, 2, 3, FMT, M>(lv, lv.data, boff, p, xh, xl, out_off);
-    bad |= gather_pair<C, 4, 5, FMT, M>(lv, lv.data, boff, p, xh, xl, out_off);
-    bad |= gather_pair<C, 6, 6, FMT, M>(lv, lv.data, boff, p, xh, xl, out_off);
-    if (bad) g.nan_flags[row >> 6] = 1;
+    gather_pair<C, 0, 1, FMT, M>(lv, lv.data, boff, p, xh, xl, out_off);
+    gather_pair<C, 2, 3, FMT, M>(lv, lv.data, boff, p, xh, xl, out_off);
+    gather_pair<C, 4, 5, FMT, M>(lv, lv.data, boff, p, xh, xl, out_off);
+    gather_pair<C, 6, 6, FMT, M>(lv, lv.data, boff, p, xh, xl, out_off);
   }
 }
 
@@ -205,7 +213,7 @@ __device__ __forceinline__ void plane4(const typename M::Raw& a, const typename 
 }
 
 template <int FMT, int V>
-__device__ __forceinline__ bool store_wsum(const float (&P)[4][V], const float (&w)[4],
+__device__ __forceinline__ void store_wsum(const float (&P)[4][V], const float (&w)[4],
                                            unsigned short* __restrict__ xh, unsigned short* __restrict__ xl,
                                            int64_t off, bool valid) {
   float r[V];
@@ -216,7 +224,6 @@ __device__ __forceinline__ bool store_wsum(const float (&P)[4][V], const float (
     r[c] = t;
   }
   store_feats<FMT, V>(xh, xl, off, r, valid);
-  return any_nan<V>(r);
 }
 
 template <int C, int FMT, int F16>
@@ -292,26 +299,23 @@ __global__ __launch_bounds__(256) void k_gather_vox_near(GatherParams g, ListVox
     // x axis -> stencil points 0, 1, 2
 #pragma unroll
     for (int k = 0; k < 4; ++k) plane4<M>(A[k][0], A[k][1], A[k][2], A[k][3], wyz, P[k]);
-    bool bad = store_wsum<FMT, V>(P, wcx, xh, xl, out_off + 0 * C, p.valid);
-    bad |= store_wsum<FMT, V>(P, wmx, xh, xl, out_off + 1 * C, p.valid);
-    bad |= store_wsum<FMT, V>(P, wpx, xh, xl, out_off + 2 * C, p.valid);
+    store_wsum<FMT, V>(P, wcx, xh, xl, out_off + 0 * C, p.valid);
+    store_wsum<FMT, V>(P, wmx, xh, xl, out_off + 1 * C, p.valid);
+    store_wsum<FMT, V>(P, wpx, xh, xl, out_off + 2 * C, p.valid);
     // y axis: planes 1,2 come from A (x slots 1,2), planes 0,3 from By; weights (x1,z1)(x2,z1)(x1,z2)(x2,z2)
     plane4<M>(By[0][0], By[0][1], By[0][2], By[0][3], wxz, P[0]);
     plane4<M>(A[1][0], A[2][0], A[1][2], A[2][2], wxz, P[1]);
     plane4<M>(A[1][1], A[2][1], A[1][3], A[2][3], wxz, P[2]);
     plane4<M>(By[1][0], By[1][1], By[1][2], By[1][3], wxz, P[3]);
-    bad |= store_wsum<FMT, V>(P, wmy, xh, xl, out_off + 3 * C, p.valid);
-    bad |= store_wsum<FMT, V>(P, wpy, xh, xl, out_off + 4 * C, p.valid);
+    store_wsum<FMT, V>(P, wmy, xh, xl, out_off + 3 * C, p.valid);
+    store_wsum<FMT, V>(P, wpy, xh, xl, out_off + 4 * C, p.valid);
     // z axis: planes 1,2 from A, planes 0,3 from Bz; weights (x1,y1)(x2,y1)(x1,y2)(x2,y2)
     plane4<M>(Bz[0][0], Bz[0][1], Bz[0][2], Bz[0][3], wxy, P[0]);
     plane4<M>(A[1][0], A[2][0], A[1][1], A[2][1], wxy, P[1]);
     plane4<M>(A[1][2], A[2][2], A[1][3], A[2][3], wxy, P[2]);
     plane4<M>(Bz[1][0], Bz[1][1], Bz[1][2], Bz[1][3], wxy, P[3]);
-    bad |= store_wsum<FMT, V>(P, wmz, xh, xl, out_off + 5 * C, p.valid);
-    bad |= store_wsum<FMT, V>(P, wpz, xh, xl, out_off + 6 * C, p.valid);
-    // a NaN anywhere (a window voxel with weight 0 holding +-inf / NaN poisons the shared sums): redo the wave's
-    // points sample by sample with the reference's skip semantics; the rows are rewritten by the same lanes
-    if (bad) g.nan_flags[row >> 6] = 1;
+    store_wsum<FMT, V>(P, wmz, xh, xl, out_off + 5 * C, p.valid);
+    store_wsum<FMT, V>(P, wpz, xh, xl, out_off + 6 * C, p.valid);
   }
 }
 
@@ -529,7 +533,6 @@ __global__ __launch_bounds__(256) void k_gather_img(GatherParams g, const void* 
         float r[M::V];
         tap_mul<M>(v[k][0], a.pr.w00, r); tap_fma<M>(v[k][1], a.pr.w01, r);
         tap_fma<M>(v[k][2], a.pr.w10, r); tap_fma<M>(v[k][3], a.pr.w11, r);
-        if (wave_any(any_nan<M::V>(r))) reduce_proj_exact<M>(v[k], a.pr, r);
         store_feats<FMT, M::V>(xh, xl, (int64_t)a.row * g.Kp + col_off + q * M::V, r, a.valid != 0);
       }
     }
@@ -577,10 +580,11 @@ __device__ __forceinline__ void put(const GatherParams& g, int64_t o, float v) {
 // lane 7 writes xyz and the zero padding.
 template <int FMT>
 __global__ __launch_bounds__(256) void k_gather_tail(GatherParams g, TailLevels tl, int xyz_off,
-                                                     int F) {
+                                                     int F, int* __restrict__ nan_tiles) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int row = t >> 3, j = t & 7;
   if (row >= g.rows) return;
+  if (nan_tiles && j == 7 && (row % kRowTile) == 0) nan_tiles[row / kRowTile] = 0;   // cleared for fc_0's probe
   const Pt p = load_point(g, row);
   const int64_t ro = (int64_t)row * g.Kp;
   if (j < LIST_N_STENCIL) {
@@ -620,8 +624,14 @@ __global__ __launch_bounds__(256) void k_gather_tail(GatherParams g, TailLevels 
   if (FMT == FMT_BF16_SPLIT) zero_pad(g.x_lo);
 }
 
-// ---- exact redo of flagged row groups (cold) ---------------------------------------------------------------
-struct FixupLevels { ListVoxLevel lv[LIST_N_VOX_LEVELS]; int off[LIST_N_VOX_LEVELS]; int n; };
+// ---- exact redo of flagged row tiles (cold) -----------------------------------------------------------------
+// grid = rows / 64; a workgroup whose 256-row tile is not flagged exits at once.  Channel counts are runtime
+// values here (one kernel for every level), every sample reloads its own 8 / 4 taps: slow and simple.
+struct FixupArgs {
+  ListVoxLevel lv[LIST_N_VOX_LEVELS]; int off[LIST_N_VOX_LEVELS]; int n;     // vector voxel levels
+  const void* img_map; const float* trans_mat; int img_f16, ms, Ct, img_off; float clamp_hi;   // img_map == NULL: none
+  const int* tile_flags;                                                       // [rows / 256]
+};
 
 template <int FMT, typename M>
 __device__ __forceinline__ void fixup_level(const GatherParams& g, const ListVoxLevel& lv, int col_off, int blk,
@@ -648,17 +658,55 @@ __device__ __forceinline__ void fixup_level(const GatherParams& g, const ListVox
   }
 }
 
+template <int FMT, typename M>
+__device__ __forceinline__ void fixup_img(const GatherParams& g, const FixupArgs& fa, int blk, const Pt* pts) {
+  const int lq = fa.Ct / M::V;
+  const int64_t img_stride = (int64_t)fa.ms * fa.ms * fa.Ct;
+  for (int item = threadIdx.x; item < kGatherRows * lq; item += 256) {
+    const int local = item / lq, q = item - local * lq;
+    const Pt p = pts[local];
+    const Proj pr = project(fa.trans_mat + p.b * 12, p.x, p.y, p.z, fa.ms, fa.Ct, fa.clamp_hi);
+    const int64_t bo = p.b * img_stride + q * M::V;
+    const typename M::Raw v[4] = {M::load(fa.img_map, bo + pr.o00), M::load(fa.img_map, bo + pr.o01),
+                                  M::load(fa.img_map, bo + pr.o10), M::load(fa.img_map, bo + pr.o11)};
+    float r[M::V];
+    reduce_proj_exact<M>(v, pr, r);
+    store_feats<FMT, M::V>(g.x_hi, g.x_lo, (int64_t)(blk * kGatherRows + local) * g.Kp + fa.img_off + q * M::V, r,
+                           p.valid);
+  }
+}
+
 template <int FMT>
-__global__ __launch_bounds__(256) void k_gather_fixup(GatherParams g, FixupLevels fl) {
+__global__ __launch_bounds__(256) void k_gather_fixup(GatherParams g, FixupArgs fa) {
   __shared__ Pt pts[kGatherRows];
   const int blk = blockIdx.x;
-  if (g.nan_flags[blk] == 0) return;
+  if (fa.tile_flags[blk / (kRowTile / kGatherRows)] == 0) return;
   if (threadIdx.x < kGatherRows) pts[threadIdx.x] = load_point(g, blk * kGatherRows + threadIdx.x);
   __syncthreads();
-  for (int l = 0; l < fl.n; ++l) {
-    if (fl.lv[l].dtype == LIST_MAP_F16) fixup_level<FMT, MapT<1>>(g, fl.lv[l], fl.off[l], blk, pts);
-    else fixup_level<FMT, MapT<0>>(g, fl.lv[l], fl.off[l], blk, pts);
+  for (int l = 0; l < fa.n; ++l) {
+    if (fa.lv[l].dtype == LIST_MAP_F16) fixup_level<FMT, MapT<1>>(g, fa.lv[l], fa.off[l], blk, pts);
+    else fixup_level<FMT, MapT<0>>(g, fa.lv[l], fa.off[l], blk, pts);
   }
+  if (fa.img_map) {
+    if (fa.img_f16) fixup_img<FMT, MapT<1>>(g, fa, blk, pts);
+    else fixup_img<FMT, MapT<0>>(g, fa, blk, pts);
+  }
+}
+
+hipError_t launch_gather_fixup(const GatherParams& g, const FeatLayout& L, const ListQueryArgs& a,
+                               const int* tile_flags, hipStream_t s) {
+  FixupArgs fa;
+  fa.n = 0;
+  for (int l = 0; l < LIST_N_VOX_LEVELS; ++l)
+    if (a.vox[l].C != 1) { fa.lv[fa.n] = a.vox[l]; fa.off[fa.n] = L.vox_off[l]; ++fa.n; }
+  fa.img_map = a.percep_feat ? nullptr : a.img_map;
+  fa.trans_mat = a.trans_mat; fa.img_f16 = a.img_dtype == LIST_MAP_F16; fa.ms = a.map_size; fa.Ct = L.img_C;
+  fa.img_off = L.img_off; fa.clamp_hi = a.clamp_hi; fa.tile_flags = tile_flags;
+  if (g.fmt == FMT_FP16)
+    hipLaunchKernelGGL(k_gather_fixup<FMT_FP16>, dim3(g.rows / kGatherRows), dim3(256), 0, s, g, fa);
+  else
+    hipLaunchKernelGGL(k_gather_fixup<FMT_BF16_SPLIT>, dim3(g.rows / kGatherRows), dim3(256), 0, s, g, fa);
+  return hipGetLastError();
 }
 
 // ---- launch ----------------------------------------------------------------------------------------
@@ -687,7 +735,7 @@ static hipError_t launch_vox_level(const GatherParams& g, const ListVoxLevel& lv
 
 template <int FMT>
 static hipError_t launch_gather_fmt(const GatherParams& g, const FeatLayout& L, const ListQueryArgs& a,
-                                    hipStream_t s) {
+                                    int* nan_tiles, hipStream_t s) {
   hipError_t e = hipSuccess;
   auto mark = [&](int stage) {
     if (a.stage_events && a.stage_events[stage]) (void)hipEventRecord((hipEvent_t)a.stage_events[stage], s);
@@ -695,14 +743,10 @@ static hipError_t launch_gather_fmt(const GatherParams& g, const FeatLayout& L, 
   int vec_level = 0;
   TailLevels tl;
   tl.n = 0;
-  FixupLevels fl;
-  fl.n = 0;
-  e = hipMemsetAsync(g.nan_flags, 0, (size_t)(g.rows / kGatherRows) * sizeof(int), s);
-  if (e != hipSuccess) return e;
   for (int l = 0; l < LIST_N_VOX_LEVELS; ++l) {
     const ListVoxLevel& lv = a.vox[l];
     if (lv.C == 1) { tl.lv[tl.n] = lv; tl.off[tl.n] = L.vox_off[l]; ++tl.n; continue; }
-    fl.lv[fl.n] = lv; fl.off[fl.n] = L.vox_off[l]; ++fl.n;
+
     switch (lv.C) {
       case 4: e = launch_vox_level<4, FMT>(g, lv, L.vox_off[l], s); break;
       case 8: e = launch_vox_level<8, FMT>(g, lv, L.vox_off[l], s); break;
@@ -732,21 +776,19 @@ static hipError_t launch_gather_fmt(const GatherParams& g, const FeatLayout& L, 
   if (e != hipSuccess) return e;
   mark(LIST_STAGE_IMG);
   hipLaunchKernelGGL(k_gather_tail<FMT>, dim3((g.rows + 31) / 32), dim3(256), 0, s, g, tl, L.xyz_off,
-                     L.F);
-  if (fl.n > 0)
-    hipLaunchKernelGGL(k_gather_fixup<FMT>, dim3(g.rows / kGatherRows), dim3(256), 0, s, g, fl);
+                     L.F, nan_tiles);
   return hipGetLastError();
 }
 
 hipError_t launch_gather(const GatherParams& g, const FeatLayout& L, const ListQueryArgs& a,
-                         hipStream_t s) {
-  return g.fmt == FMT_FP16 ? launch_gather_fmt<FMT_FP16>(g, L, a, s)
-                           : launch_gather_fmt<FMT_BF16_SPLIT>(g, L, a, s);
+                         int* nan_tiles, hipStream_t s) {
+  return g.fmt == FMT_FP16 ? launch_gather_fmt<FMT_FP16>(g, L, a, nan_tiles, s)
+                           : launch_gather_fmt<FMT_BF16_SPLIT>(g, L, a, nan_tiles, s);
 }
 
 // ---- diagnostics: X (gather order, hi+lo) -> out[B][F][N] in the reference order ---------------------
 __global__ __launch_bounds__(256) void k_features_out(GatherParams g, FeatLayout L,
-                                                      float* __restrict__ out) {
+                                                      float* __restrict__ out, int* __restrict__ nan_tiles) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t total = (int64_t)g.n_valid * L.Kp;
   if (i >= total) return;
@@ -756,16 +798,16 @@ __global__ __launch_bounds__(256) void k_features_out(GatherParams g, FeatLayout
   const int64_t gp = g.p_begin + (g.order ? g.order[row] : row);
   const int b = (int)(gp / g.N);
   const int n = (int)(gp - (int64_t)b * g.N);
-  out[((int64_t)b * L.F + kr) * g.N + n] =
-      g.fmt == FMT_FP16 ? h2f(g.x_hi[i]) : bf2f(g.x_hi[i]) + bf2f(g.x_lo[i]);
+  const float v = g.fmt == FMT_FP16 ? h2f(g.x_hi[i]) : bf2f(g.x_hi[i]) + bf2f(g.x_lo[i]);
+  out[((int64_t)b * L.F + kr) * g.N + n] = v;
+  if (nan_tiles && v != v) nan_tiles[row / kRowTile] = 1;        // same trigger as fc_0's epilogue
 }
 
-hipError_t launch_features_out(const GatherParams& g, const FeatLayout& L, float* out, int B,
+hipError_t launch_features_out(const GatherParams& g, const FeatLayout& L, float* out, int* nan_tiles,
                                hipStream_t s) {
-  (void)B;
   const int64_t total = (int64_t)g.n_valid * L.Kp;
   hipLaunchKernelGGL(k_features_out, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g, L,
-                     out);
+                     out, nan_tiles);
   return hipGetLastError();
 }
 

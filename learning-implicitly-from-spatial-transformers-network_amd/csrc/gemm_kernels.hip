@@ -192,15 +192,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
   } else if (EPI == EPI_RELU_SPLIT) {
     const int64_t row_base = m0 + wm * 128;
     const int col_base = n0 + wn * 64;
+    bool bad = false;
     staged_epilogue(acc, smem, wave, lane, [&](int r, int c8, const float (&v)[8]) {
       float o[8];
       const float4 b0 = p.bias ? *(const float4*)(p.bias + col_base + c8) : make_float4(0.f, 0.f, 0.f, 0.f);
       const float4 b1 = p.bias ? *(const float4*)(p.bias + col_base + c8 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = relu_nan(v[e] + bb[e]);
+      for (int e = 0; e < 8; ++e) { o[e] = relu_nan(v[e] + bb[e]); bad = bad || (o[e] != o[e]); }
       store8_planes<FP16>(p.out_hi, p.out_lo, (row_base + r) * p.ldo + col_base + c8, o);
     });
+    // a NaN in a feature row reaches every output column of that row: flag the row tile for the exact redo of
+    // its gathers (gather_kernels.hip: exact border semantics)
+    if (p.nan_tiles && __builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) p.nan_tiles[m0 / BM] = 1;
   } else if (EPI == EPI_RELU_SPLIT || EPI == EPI_F32) {
     // one base pointer per output plane; per-element offsets are (wave-uniform row term) + lane term
     const int ld = EPI == EPI_F32 ? p.N : p.ldo;
@@ -294,6 +298,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(GemmParams p) {
   const int ntiles = (p.M / BM) * tiles_n;
   const int tile = xcd_contiguous_block(blockIdx.x, ntiles);
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  if (p.tile_gate && p.tile_gate[tile / tiles_n] == 0) return;      // gated re-run (exact border semantics): uniform exit
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -411,6 +416,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_pp(GemmParams p) {
   const int ntiles = (p.M / BM) * tiles_n;
   const int tile = xcd_contiguous_block(blockIdx.x, ntiles);
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  if (p.tile_gate && p.tile_gate[tile / tiles_n] == 0) return;      // gated re-run (exact border semantics): uniform exit
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -538,6 +544,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt16(GemmParams p) {
   const int ntiles = (p.M / BM) * tiles_n;
   const int tile = xcd_contiguous_block(blockIdx.x, ntiles);
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  if (p.tile_gate && p.tile_gate[tile / tiles_n] == 0) return;      // gated re-run (exact border semantics): uniform exit
 
   f32x4v acc[8][4];
 #pragma unroll

@@ -101,7 +101,6 @@ GatherParams make_gather(const ListQueryArgs* a, const FeatLayout& L, const Work
   g.Kp = L.Kp;
   g.fmt = a->precision == LIST_PREC_FP16 ? FMT_FP16 : FMT_BF16_SPLIT;
   g.order = nullptr; g.order_img = nullptr; g.row_of = nullptr;
-  g.nan_flags = (int*)((char*)a->workspace + ws.nan_flags);
   return g;
 }
 
@@ -319,7 +318,8 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
       }
     }
     mark(LIST_STAGE_SORT);
-    e = launch_gather(g, L, chunk_args, s);
+    int* nan_tiles = (int*)(wsb + ws.nan_tiles);
+    e = launch_gather(g, L, chunk_args, nan_tiles, s);
     if (e != hipSuccess) return hip_fail(e, "gather launch");
     mark(LIST_STAGE_TAIL);
 
@@ -334,9 +334,20 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
     gp.out_hi = (unsigned short*)(wsb + ws.h1_hi);
     gp.out_lo = terms == 3 ? (unsigned short*)(wsb + ws.h1_lo) : nullptr;
     gp.ldo = a->H1;
+    // exact border semantics (gather_kernels.hip): fc_0 flags the row tiles whose output holds a NaN, the gathers
+    // of those tiles are redone with the reference's skip semantics and fc_0 runs again for them.  On finite
+    // inputs both gated launches exit at their first instruction.
+    gp.nan_tiles = nan_tiles;
     e = launch_gemm(gp, terms, EPI_RELU_SPLIT, s);
     if (e != hipSuccess) return hip_fail(e, "fc_0 launch");
     mark(LIST_STAGE_FC0);
+    e = launch_gather_fixup(g, L, chunk_args, nan_tiles, s);
+    if (e != hipSuccess) return hip_fail(e, "gather fix-up launch");
+    gp.nan_tiles = nullptr; gp.tile_gate = nan_tiles;
+    e = launch_gemm(gp, terms, EPI_RELU_SPLIT, s);
+    if (e != hipSuccess) return hip_fail(e, "gated fc_0 launch");
+    gp.tile_gate = nullptr;
+    mark(LIST_STAGE_EXACT);
     // fc_1 + ReLU
     gp.a_hi = wsb + ws.h1_hi; gp.a_lo = wsb + ws.h1_lo;
     gp.w_hi = wp + pk.w1_hi; gp.w_lo = wp + pk.w1_lo;
@@ -378,9 +389,14 @@ int list_gather_features_fwd(const ListQueryArgs* a, float* out, void* stream) {
     const int n_valid = (int)((P - p0 < rows) ? (P - p0) : rows);
     const int crow = (n_valid + kRowTile - 1) / kRowTile * kRowTile;
     GatherParams g = make_gather(a, L, ws, p0, n_valid, crow);
-    hipError_t e = launch_gather(g, L, *a, s);
+    int* nan_tiles = (int*)((char*)a->workspace + ws.nan_tiles);
+    hipError_t e = launch_gather(g, L, *a, nan_tiles, s);
     if (e != hipSuccess) return hip_fail(e, "gather launch");
-    e = launch_features_out(g, L, out, a->B, s);
+    e = launch_features_out(g, L, out, nan_tiles, s);
+    if (e != hipSuccess) return hip_fail(e, "features_out launch");
+    e = launch_gather_fixup(g, L, *a, nan_tiles, s);          // exact redo of the tiles that showed a NaN
+    if (e != hipSuccess) return hip_fail(e, "gather fix-up launch");
+    e = launch_features_out(g, L, out, nullptr, s);
     if (e != hipSuccess) return hip_fail(e, "features_out launch");
   }
   return LIST_OK;
@@ -500,7 +516,21 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
       (void)hipEventRecord((hipEvent_t)ga->stage_events[stage], s);
   };
   hipError_t e = hipSuccess;
-#define LIST_TRY(call, what) do { e = (call); if (e != hipSuccess) return hip_fail(e, what); } while (0)
+  // a failure after the fork must not leave the auxiliary streams running past the call: the caller frees the
+  // workspace and the outputs as soon as it sees the error.  join_and_fail() orders `s` behind whatever has been
+  // enqueued on them so far, then reports.
+  hipStream_t j_direct = s, j_window = s;
+  auto join_and_fail = [&](hipError_t err, const char* what) -> int {
+    for (hipStream_t from : {j_direct, j_window}) {
+      if (from == s) continue;
+      hipEvent_t ev;
+      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) continue;
+      if (hipEventRecord(ev, from) == hipSuccess) (void)hipStreamWaitEvent(s, ev, 0);
+      (void)hipEventDestroy(ev);
+    }
+    return hip_fail(err, what);
+  };
+#define LIST_TRY(call, what) do { e = (call); if (e != hipSuccess) return join_and_fail(e, what); } while (0)
 
   const int* order = a->no_sort ? nullptr : (const int*)(fw + ws.order);
   float* scale = (float*)(bwp + bw.scale);
@@ -512,6 +542,7 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   hipStream_t s_direct = s, s_window = s;
   const bool forked = ga->aux_streams[0] && ga->aux_streams[1];
   if (forked) { s_direct = (hipStream_t)ga->aux_streams[0]; s_window = (hipStream_t)ga->aux_streams[1]; }
+  j_direct = s_direct; j_window = s_window;
   auto hand_over = [&](hipStream_t from, hipStream_t to) -> hipError_t {      // `to` continues after `from`'s work so far
     if (from == to) return hipSuccess;
     hipEvent_t ev;

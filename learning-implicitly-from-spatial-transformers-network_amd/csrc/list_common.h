@@ -46,6 +46,9 @@ __device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 __device__ __forceinline__ float sat_h(float x) {
+#ifdef LIST_SAT_H_MINMAX          // A/B only: the round-1 clamp (a NaN becomes -65504)
+  return fminf(fmaxf(x, -65504.f), 65504.f);
+#endif
   const float c = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
   return (x != x) ? x : c;
 }
@@ -70,6 +73,13 @@ __device__ __forceinline__ uint2 half4(const float4& v) {
 #else
   return make_uint2(f2h2(v.x, v.y), f2h2(v.z, v.w));
 #endif
+}
+// no clamp: for values known to lie inside the fp16 range (interpolations of fp16 maps: a convex combination
+// of halfs is at most 65504 (1 + 2^-22), which still rounds to 65504); NaN stays NaN
+__device__ __forceinline__ uint2 half4_inrange(const float4& v) {
+  const f32x2_t a = {v.x, v.y}, b = {v.z, v.w};
+  return make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(a, f16x2_t)),
+                    __builtin_bit_cast(unsigned, __builtin_convertvector(b, f16x2_t)));
 }
 // ReLU as torch computes it: a NaN stays a NaN (v_max_f32 would return 0)
 __device__ __forceinline__ float relu_nan(float x) { return x < 0.f ? 0.f : x; }
@@ -277,7 +287,7 @@ struct Workspace {
   size_t x_hi, x_lo, h1_hi, h1_lo, h2_hi, h2_lo;     // byte offsets
   size_t order, keys, bins;                          // point sort: int32 [rows], [rows], [kSortBins]
   size_t order_img, row_of, keys2;                   // pixel order for the 2-D gather; point -> X row
-  size_t nan_flags;                                  // int32 [rows / 64]
+  size_t nan_tiles;                                  // int32 [rows / 256]: tiles whose fc_0 output holds a NaN
   size_t total;
 };
 inline size_t workspace_row_bytes(int Kp, int H1, int H2) {
@@ -295,7 +305,7 @@ inline Workspace workspace_layout(int64_t rows, int Kp, int H1, int H2) {
   w.order_img = take((size_t)rows * 4); w.row_of = take((size_t)rows * 4);
   w.keys2 = take((size_t)rows * 4);
   w.bins = take((size_t)kSortBins * 4);
-  w.nan_flags = take((size_t)(rows / kGatherRows + 1) * 4);
+  w.nan_tiles = take((size_t)(rows / kRowTile + 1) * 4);
   w.total = o;
   return w;
 }
@@ -314,7 +324,6 @@ struct GatherParams {
   const int* order;           // row -> chunk-local point index (Morton order), or nullptr
   const int* order_img;       // 2-D gather: slot -> chunk-local point index (pixel order), or nullptr
   const int* row_of;          // chunk-local point index -> X row (inverse of `order`)
-  int* nan_flags;             // [rows / 64]: set by a voxel gather whose result holds a NaN (k_gather_fixup)
 };
 
 struct GemmParams {
@@ -330,6 +339,8 @@ struct GemmParams {
   const unsigned short* mask; int ldmask;                    // EPI_MASK_SPLIT: keep acc where mask plane != 0
   void* dx; int dx_f16; int n_store;                         // EPI_DX: [M][ldo] fp16/fp32, columns < n_store
   int plain_loop;                                            // diagnostics: never take the ping-pong schedule
+  int* nan_tiles;                                            // EPI_RELU_SPLIT: nan_tiles[m0 / 256] = 1 if the tile's output holds a NaN
+  const int* tile_gate;                                      // run only the row tiles with tile_gate[m0 / 256] != 0
 };
 
 // EPI_MASK_SPLIT: out = acc where the saved activation is positive (ReLU backward), no bias;
@@ -357,10 +368,14 @@ hipError_t launch_split(const float* x, unsigned short* hi, unsigned short* lo, 
 struct SortBuffers { int* order; int* order_img; int* row_of; int* keys; int* keys2; int* bins; };
 hipError_t launch_sort_points(const GatherParams& g, const ListQueryArgs& a, const SortBuffers& sb,
                               hipStream_t s);
+// nan_tiles: int32 [rows / 256], cleared by the last gather kernel (the flags of fc_0's NaN probe)
 hipError_t launch_gather(const GatherParams& g, const FeatLayout& L, const ListQueryArgs& a,
-                         hipStream_t s);
-hipError_t launch_features_out(const GatherParams& g, const FeatLayout& L, float* out, int B,
+                         int* nan_tiles, hipStream_t s);
+hipError_t launch_features_out(const GatherParams& g, const FeatLayout& L, float* out, int* nan_tiles,
                                hipStream_t s);
+// exact (reference skip semantics) redo of the voxel and 2-D gathers for the 256-row tiles flagged in tile_flags
+hipError_t launch_gather_fixup(const GatherParams& g, const FeatLayout& L, const ListQueryArgs& a,
+                               const int* tile_flags, hipStream_t s);
 hipError_t launch_percep_pool(const ListPoolArgs& a, hipStream_t s);
 hipError_t launch_gemm(const GemmParams& p, int terms, int epi, hipStream_t s);
 

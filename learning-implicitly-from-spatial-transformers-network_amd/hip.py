@@ -95,10 +95,10 @@ N_BWD_STAGES = 11
 BWD_STAGE_NAMES = ("head", "wgrad_fc2", "dgrad_fc2", "wgrad_fc1", "dgrad_fc1", "dgrad_fc0", "wgrad_fc0",
                    "scatter_vox", "img_map_grad", "trans_mat_grad")
 
-N_STAGES = 12
+N_STAGES = 13
 # interval i = [event i, event i+1]: the kernel (group) that ends at stage i+1 of include/list_hip.h
 STAGE_NAMES = ("sort_points", "gather_vox_l1", "gather_vox_l2", "gather_vox_l3", "gather_vox_l4",
-               "gather_vox_l5", "gather_img", "gather_tail", "fc_0", "fc_1", "fc_2_out")
+               "gather_vox_l5", "gather_img", "gather_tail", "fc_0", "exact_redo", "fc_1", "fc_2_out")
 
 
 class ListPoolArgs(C.Structure):
@@ -325,24 +325,30 @@ def prep_mlp_weights_bwd(params, vox_C, img_C=1024, precision="bf16x3"):
     return packed
 
 
-_workspaces = {}
+# Scratch of the forward (X, H1, H2, point orders: 1.2 - 4.6 GB).  It lives in THREAD-LOCAL storage, keyed by
+# (device, stream): two threads, or two streams of one thread, never share one (the kernels of a call keep using
+# it after the call has returned), and it cannot outlive its thread -- nn.DataParallel starts fresh threads for
+# every forward (reference train.py:126), whose workspaces go back to PyTorch's caching allocator when they end.
+_tls = threading.local()
 
 
 def _workspace(device, nbytes):
-    """One grow-only workspace per (device, stream, thread): re-entrant under DataParallel threads."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream, threading.get_ident())
-    ws = _workspaces.get(key)
+    cache = _tls.__dict__.setdefault("workspaces", {})
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = cache.get(key)
     if ws is None or ws.numel() < nbytes:
+        cache.pop(key, None)                   # release the smaller one first
         ws = None
-        _workspaces.pop(key, None)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
-        _workspaces[key] = ws
+        cache[key] = ws
     return ws
 
 
 def release_workspaces():
-    _workspaces.clear()
-    _aux_streams.clear()
+    """Drop the calling thread's cached workspaces (other threads' die with them) and the idle side streams."""
+    _tls.__dict__.pop("workspaces", None)
+    with _aux_lock:
+        _aux_pool.clear()
 
 
 def _fill_query_args(query, perm, scale, vox, packed, precision, trans_mat=None, img=None,
@@ -443,17 +449,30 @@ def sdf_query(query, trans_mat, img, vox, packed, perm=(2, 1, 0), scale=2.0, pre
     return sdf
 
 
-_aux_streams = {}
+# Side streams for the forked stages of list_sdf_query_bwd: a per-device pool of pairs, checked out for the
+# duration of ONE call (the call joins them back into the caller's stream before it returns, so the next
+# borrower's work simply queues behind on them).  Bounded by the number of concurrent callers, not by the
+# number of threads that ever ran.
+_aux_pool = {}
+_aux_lock = threading.Lock()
 
 
-def _aux(device):
-    """Two side streams per (device, thread) for the forked stages of list_sdf_query_bwd."""
-    key = (device.index, threading.get_ident())
-    st = _aux_streams.get(key)
-    if st is None:
-        st = (torch.cuda.Stream(device), torch.cuda.Stream(device))
-        _aux_streams[key] = st
-    return st
+class _AuxStreams:
+    def __init__(self, device):
+        self.device = device
+
+    def __enter__(self):
+        with _aux_lock:
+            free = _aux_pool.setdefault(self.device.index, [])
+            self.pair = free.pop() if free else None
+        if self.pair is None:
+            self.pair = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
+        return self.pair
+
+    def __exit__(self, *exc):
+        with _aux_lock:
+            _aux_pool.setdefault(self.device.index, []).append(self.pair)
+        return False
 
 
 def sdf_query_backward(ctx, grad_sdf, packed_bwd, want_mlp=True, want_img=True, want_vox=True,
@@ -521,11 +540,29 @@ def sdf_query_backward(ctx, grad_sdf, packed_bwd, want_mlp=True, want_img=True, 
     if stage_events is not None:
         ga.stage_events = C.cast(stage_events, C.POINTER(C.c_void_p))
     if overlap:        # dW0 | atomic scatters | window scatters | gathers run side by side (joined before return)
-        a0, a1 = _aux(dev)
-        ga.aux_streams[0], ga.aux_streams[1] = a0.cuda_stream, a1.cuda_stream
+        with _AuxStreams(dev) as (a0, a1), torch.cuda.device(dev):
+            ga.aux_streams[0], ga.aux_streams[1] = a0.cuda_stream, a1.cuda_stream
+            _check(lib.list_sdf_query_bwd(C.byref(ga), _stream()), "list_sdf_query_bwd")
+            # every buffer of this call (ws, the outputs) was also used on the side streams
+            for t in [ws, g] + _tensors_of(out):
+                t.record_stream(a0)
+                t.record_stream(a1)
+        return out
     with torch.cuda.device(dev):
         _check(lib.list_sdf_query_bwd(C.byref(ga), _stream()), "list_sdf_query_bwd")
     return out
+
+
+def _tensors_of(out):
+    ts = []
+    for v in out.values():
+        if torch.is_tensor(v):
+            ts.append(v)
+        elif isinstance(v, dict):
+            ts += list(v.values())
+        else:
+            ts += list(v)
+    return ts
 
 
 def _level_descriptors(like, img_C):

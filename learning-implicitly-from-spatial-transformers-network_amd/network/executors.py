@@ -80,6 +80,17 @@ class LIST:
                            - (1 - w) * torch.mean((1 - occ_gt) * torch.log(1 - occ + 1e-8)))
         loss = {"occ_loss": occ_loss}
         loss.update(self.loss_sdf(sdf_pred, sdf_gt))
+        rank, world = parallel.world_info()
+        if world > 1:
+            # One process per GPU holds B_local images.  The reference evaluates SDFLoss over the whole batch
+            # (network/losses.py:21-22, nn.DataParallel gathers the outputs): ONE all-gather of the fp32 SDF shards
+            # (and of their targets) gives every rank that value; gradients keep flowing through the local term,
+            # whose DDP average over the ranks IS the full-batch gradient (equal shards).
+            full = self.loss_sdf(parallel.gather_sdf_shards(sdf_pred.detach()),
+                                 parallel.gather_sdf_shards(sdf_gt.detach()))
+            for k in full:
+                loss[k] = parallel.full_batch_value(loss[k], full[k])
+            loss["occ_loss"] = parallel.full_batch_value(occ_loss, parallel.all_reduce_mean(occ_loss))
         return loss
 
     def train(self, batch, calc_loss=True):
@@ -104,6 +115,8 @@ class LIST:
         feat_l2, vox_feat, transmat, _, occ = net.encode(img, transmat)
         total = res ** 3
         rank, world = parallel.world_info() if shard else (0, 1)
+        if world > 1:        # every rank samples rank 0's maps: sharded == unsharded bit for bit (parallel.py)
+            parallel.broadcast_from_rank0(list(feat_l2) + list(vox_feat) + [transmat, occ])
         begin, end = parallel.shard_range(total, rank, world)
         out = torch.empty((end - begin,), dtype=torch.float32, device=dev)
         for s in range(begin, end, self.test_pointnum):

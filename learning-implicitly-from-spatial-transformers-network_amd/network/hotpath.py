@@ -37,15 +37,18 @@ class _Cache:
     """Remembers the last prepared object for a tuple of source tensors, e.g. across the chunk loop
     of executors.LIST.test.  A hit needs the SAME tensor objects (held strongly here, so neither
     their ids nor their storage can be recycled by a later, different tensor) with unchanged
-    version counters; anything else -- new encoder outputs, an in-place update, an optimizer
-    step -- rebuilds."""
+    version counters, storage addresses, devices and dtypes; anything else -- new encoder outputs, an
+    in-place update, an optimizer step, module.to() / .float() (which swap param.data) -- rebuilds.
+    Writes through `.data` bump no version counter: trainable parameters are therefore never served from
+    a cache while gradients are enabled (sdf_query re-packs them every step), and VoxelDecoder.invalidate()
+    drops everything on train() / load_state_dict() / _apply()."""
 
     def __init__(self):
         self.sources, self.versions, self.value = None, None, None
 
     def get(self, tensors, make):
         tensors = tuple(tensors)
-        versions = tuple(t._version for t in tensors)
+        versions = tuple((t._version, t.data_ptr(), t.device, t.dtype) for t in tensors)
         hit = (self.sources is not None and len(self.sources) == len(tensors)
                and all(a is b for a, b in zip(self.sources, tensors)) and versions == self.versions)
         if not hit:
@@ -187,7 +190,9 @@ def sdf_query(query, trans_mat, img_maps, vox_maps, mlp_params, *, perm=(2, 1, 0
               map_size=137, precision="bf16x3", percep_feat=None, caches=None):
     """sdf [B,N] for raw queries; mlp_params: dict with the reference's fc_* keys."""
     require_hip(query, "query")
-    caches = caches or {}
+    # nn.DataParallel replicas share the module's cache dict (replicate() copies attributes by reference) and run
+    # in one thread per device: every device gets its own slots
+    caches = (caches if caches is not None else {}).setdefault(("device", query.device.index), {})
     query = _f32(query)
     # a half-precision producer's vector levels stay fp16 (used where they lie); its scalar level is read as fp32
     vox_maps = [v if (v.dtype == torch.float16 and v.shape[1] > 1) else _f32(v) for v in vox_maps]
@@ -202,9 +207,13 @@ def sdf_query(query, trans_mat, img_maps, vox_maps, mlp_params, *, perm=(2, 1, 0
     vox = caches.setdefault("vox:" + md, _Cache()).get(
         vox_maps, lambda: hip.prep_vox_maps([v.detach() for v in vox_maps], md))
     img_C = img.channels if img is not None else percep_feat.shape[1]
-    packed = caches.setdefault("mlp:" + str(precision), _Cache()).get(
-        mlp, lambda: hip.prep_mlp_weights({k: t.detach() for k, t in zip(MLP_KEYS, mlp)},
-                                          vox.channels, img_C, precision))
+    mlp_dict = {k: t.detach() for k, t in zip(MLP_KEYS, mlp)}
+    training = torch.is_grad_enabled() and any(t.requires_grad for t in mlp)
+    if training:          # parameters move every step (and `.data` writes are invisible to a cache): pack afresh
+        packed = hip.prep_mlp_weights(mlp_dict, vox.channels, img_C, precision)
+    else:
+        packed = caches.setdefault("mlp:" + str(precision), _Cache()).get(
+            mlp, lambda: hip.prep_mlp_weights(mlp_dict, vox.channels, img_C, precision))
 
     def run():
         return hip.sdf_query(query.detach(), trans_mat.detach() if trans_mat is not None else None,
@@ -223,10 +232,16 @@ def sdf_query(query, trans_mat, img_maps, vox_maps, mlp_params, *, perm=(2, 1, 0
                                  precision=precision, save_for_backward=True,
                                  percep_feat=pf_det[:, :, n0:n1] if pf_det is not None else None)
 
+        # the transposed copies for the data gradients are taken NOW, from the same parameter values as `packed`
+        # (a lazy build at backward time could see parameters an optimizer or EMA step has moved in between)
+        if training:
+            packed_b = hip.prep_mlp_weights_bwd(mlp_dict, vox.channels, img_C, precision)
+        else:
+            packed_b = caches.setdefault("mlpT:" + str(precision), _Cache()).get(
+                mlp, lambda: hip.prep_mlp_weights_bwd(mlp_dict, vox.channels, img_C, precision))
+
         def packed_bwd():
-            return caches.setdefault("mlpT:" + str(precision), _Cache()).get(
-                mlp, lambda: hip.prep_mlp_weights_bwd({k: t.detach() for k, t in zip(MLP_KEYS, mlp)},
-                                                      vox.channels, img_C, precision))
+            return packed_b
         state = {"run": run_saving, "packed_bwd": packed_bwd, "percep": percep_feat is not None,
                  "n_img": len(img_maps), "shape": (query.shape[0], query.shape[1])}
         lead = percep_feat if percep_feat is not None else trans_mat

@@ -26,7 +26,8 @@ class PerceptualPooling(nn.Module):
         self._caches = {}
 
     def prepared(self, img_featuremaps):
-        return self._caches.setdefault("img", hotpath._Cache()).get(
+        dev = img_featuremaps[0].device.index          # DataParallel replicas share this dict: one slot per device
+        return self._caches.setdefault(("img", dev), hotpath._Cache()).get(
             list(img_featuremaps),
             lambda: hip.prep_img_maps([m.detach().float() for m in img_featuremaps], self.map_size))
 
@@ -59,6 +60,27 @@ class VoxelDecoder(nn.Module):
     def mlp_params(self):
         return {f"{n}.{k}": getattr(self.fc[n], k) for n in ("fc_0", "fc_1", "fc_2", "fc_out")
                 for k in ("weight", "bias")}
+
+    # prepared copies (packed MLP planes, channels-last maps) are cached per device in self._caches; anything that
+    # can change parameters behind the version counters drops them
+    def invalidate(self):
+        self._caches.clear()
+
+    def train(self, mode=True):
+        self.invalidate()
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate()
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.invalidate()
+        return super().load_state_dict(*args, **kwargs)
+
+    def _load_from_state_dict(self, *args, **kwargs):        # reached when a PARENT module loads a checkpoint
+        self.invalidate()
+        return super()._load_from_state_dict(*args, **kwargs)
 
 
 class VoxelDecoder2(VoxelDecoder):

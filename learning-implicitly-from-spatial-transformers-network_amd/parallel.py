@@ -82,3 +82,51 @@ def full_batch_sdf_loss(sdf_local, targets_local, sdf_scale=1.0, group=None):
     pred = gather_sdf_shards(sdf_local, group=group)
     tgt = gather_sdf_shards(targets_local, group=group)
     return torch.mean(((tgt * sdf_scale - pred) ** 2).sum(-1))
+
+
+def full_batch_value(local, full):
+    """`local` for the gradient, `full` for the value: a scalar whose forward value is the full-batch number
+    (identical on every rank) while autograd sees only this rank's term.  With equal shards DistributedDataParallel's
+    gradient average over the ranks is then exactly the gradient of the full-batch loss."""
+    return local + (full.detach() - local.detach())
+
+
+def all_reduce_mean(value, group=None):
+    """Mean over the ranks of a (detached) scalar / small tensor."""
+    rank, world = world_info(group)
+    if world == 1:
+        return value.detach()
+    v = value.detach().clone()
+    if v.is_cuda and dist.get_backend(group) != "nccl":
+        host = v.cpu()
+        dist.all_reduce(host, group=group)
+        return (host / world).to(v.device)
+    dist.all_reduce(v, group=group)
+    return v / world
+
+
+def broadcast_from_rank0(tensors, group=None):
+    """Overwrite every tensor in `tensors` (same shapes on all ranks) with rank 0's values, in place.  Used by the
+    sharded inference: every rank encodes the image (for shapes, dtypes and memory formats), then takes rank 0's
+    maps, so that the sharded SDF grid is the unsharded one bit for bit even though MIOpen's convolutions are not
+    run-to-run deterministic."""
+    rank, world = world_info(group)
+    if world == 1:
+        return tensors
+    for t in tensors:
+        if t.is_cuda and dist.get_backend(group) != "nccl":
+            host = t.detach().cpu().contiguous()
+            dist.broadcast(host, src=0, group=group)
+            t.detach().copy_(host)
+        elif t.is_contiguous():
+            dist.broadcast(t.detach(), src=0, group=group)
+        else:                                   # channels-last maps: broadcast the dense storage order
+            flat = t.detach().permute(*_storage_order(t)).contiguous()
+            dist.broadcast(flat, src=0, group=group)
+            t.detach().permute(*_storage_order(t)).copy_(flat)
+    return tensors
+
+
+def _storage_order(t):
+    """Dimension order from the largest stride to the smallest (the permutation that makes `t` contiguous)."""
+    return sorted(range(t.dim()), key=lambda d: (-t.stride(d), d))

@@ -50,6 +50,8 @@ def train_epoch(epoch, executor, optimizer, data_iter, config, writer=None):
     totals = {"total_loss": 0.0}
     t_epoch = time.time()
     steps = 0
+    # Losses are the reference's FULL-BATCH values on every rank (executors.LIST.calc_loss gathers the SDF shards:
+    # one RCCL all-gather per step), so the epoch mean that picks best_model_train is the same number everywhere.
     for batch_idx, batch in enumerate(data_iter):
         t_iter = time.time()
         _, batch_loss = executor.train(batch=batch, calc_loss=True)
@@ -118,7 +120,13 @@ def train(config):
         config.cuda = False
 
     model = utils.get_class(config.model)(config).to(config.device)
-    if config.warm_start:
+    # Order of the reference (train.py:141-228): the optimizer covers ALL parameters (a reference-written
+    # best_model_train.pt.tar holds Adam state for every one of them; frozen parameters simply never get a
+    # gradient and Adam skips them); a resume checkpoint wins over the warm start, which -- with its freezing of
+    # im_encoder / point_decoder -- only happens when there is nothing to resume from.
+    resume = config.checkpoint_dir + "best_model_train.pt.tar"
+    resuming = bool(config.load_pretrain and os.path.exists(resume))
+    if config.warm_start and not resuming:
         _warm_start(model, config)
     model = wrap_model(model, config)
 
@@ -127,12 +135,13 @@ def train(config):
     train_iter = torch.utils.data.DataLoader(trainset, batch_size=config.train_batch_size,
                                              shuffle=sampler is None, sampler=sampler,
                                              num_workers=config.num_workers, drop_last=True)
-    optimizer = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=config.lr,
+    optimizer = torch.optim.Adam(model.parameters(), lr=config.lr,
                                  betas=(config.beta1, 0.999), weight_decay=config.weight_decay)
     epoch, best_train = 0, 1e3
-    resume = config.checkpoint_dir + "best_model_train.pt.tar"
-    if config.load_pretrain and os.path.exists(resume):
+    if resuming:
         epoch, model, optimizer, best = utils.load_checkpoint(resume, model, optimizer)
+        if best is not None:
+            best_train = float(best)          # (the reference forgets this and overwrites its best model after a resume)
         print(f"pretrained model loaded at epoch: {epoch}, best train loss: {best}")
     rank0 = (not dist.is_initialized()) or dist.get_rank() == 0
     writer = _summary_writer(config.results_dir + "/summary") if rank0 else None
