@@ -112,17 +112,21 @@ def _exists_h5(path):
 
 
 def _read_shape_ids(filename):
+    """Datasets.py:293-298: one id per line, only the newline stripped (a blank line is an id that matches no
+    shape directory and drops out at the existence test, as in the reference)."""
     with open(filename) as f:
-        return [line.strip() for line in f if line.strip()]
+        return [line.strip("\n") for line in f.readlines()]
 
 
 def _load_image(fn, config, train, rng):
-    """PNG -> float32 [3,H,W] in [0,1], channels in the reference's order: it reads with cv2.imread
-    (Datasets.py:300-304), so plane 0 is BLUE -- checkpoints trained there expect that.  ToTensor on a float array
-    only transposes and Normalize((0,)*3, (1,)*3) is the identity (Datasets.py:171-173).  The horizontal flip is
-    applied to the array in training when configured; colour jitter needs torchvision and says so."""
+    """PNG -> float32 [3,H,W] in [0,1], channels as the reference's LIVE reader yields them: PIL
+    `Image.open(..).convert('RGB')` followed by T.ToTensor() (Datasets.py:45,213-214,270-271 and :35,171), i.e.
+    plane 0 is RED and values are uint8 / 255.  (The cv2 `read_rgba_image` at Datasets.py:300-304 is dead code:
+    its call sites at :211 and :269 are commented out.)  Normalize((0,)*3, (1,)*3) is the identity (:171-173).
+    The horizontal flip is applied to the array in training when configured; colour jitter needs torchvision
+    and says so."""
     from PIL import Image
-    a = np.asarray(Image.open(fn).convert("RGB"), dtype=np.float32)[:, :, ::-1] / np.float32(255.0)
+    a = np.asarray(Image.open(fn).convert("RGB"), dtype=np.float32) / np.float32(255.0)
     if train and getattr(config, "random_h_flip", False) and rng.random() < 0.5:
         a = a[:, ::-1]
     if train and getattr(config, "color_jitter", False):
@@ -132,6 +136,7 @@ def _load_image(fn, config, train, rng):
 
 class _FileBase(data.Dataset):
     points_file = "sampled_points.h5"
+    needs_images = False
 
     def __init__(self, config, status="train", max_train_shapes=2000):
         self.config, self.status = config, status
@@ -147,7 +152,9 @@ class _FileBase(data.Dataset):
             for shape_id in shape_ids:
                 rgb_dir = os.path.join(config.image_dir, cat_id, shape_id, "easy")
                 h5_fn = os.path.join(config.h5_dir, cat_id, shape_id, self.points_file)
-                if _exists_h5(h5_fn) and os.path.isdir(rgb_dir):
+                # IM2SDF lists a shape when its sampled_points.h5 exists (Datasets.py:186); IM2PointFarthest also
+                # wants the image directory (Datasets.py:80)
+                if shape_id and _exists_h5(h5_fn) and (not self.needs_images or os.path.isdir(rgb_dir)):
                     self.datalist.append({"rgba_dir": rgb_dir, "h5_fn": h5_fn, "cat_id": cat_id, "shape_id": shape_id})
         self.datasize = len(self.datalist)
 
@@ -228,6 +235,7 @@ class FileIM2SDF(_FileBase):
 class FileIM2PointFarthest(_FileBase):
     """Datasets.py:56-137."""
     points_file = "farthest_pointclouds.h5"
+    needs_images = True
 
     def __init__(self, config, status="train"):
         super().__init__(config, status, max_train_shapes=2500)

@@ -109,6 +109,7 @@ def main():
     print("aux written")
     grad_goldens(torch, dec, pool)
     model_goldens(torch)
+    dataset_goldens(torch)
 
 
 GRAD_W0_ROW_STEP = 8
@@ -203,8 +204,157 @@ def model_goldens(torch):
           float(sdf.abs().max()), float(sdf_tm.abs().max()))
 
 
+class _NpzH5File:
+    """h5py.File stand-in for the GENERATOR only (h5py is not in this image): the same keys, kept in an .npz next to
+    the .h5 name.  Covers what the reference's datasets use: f[key][:], np.asarray(f[key]), keys(),
+    create_dataset(name, data=, compression=), close(), with-statement."""
+
+    def __init__(self, path, mode="r"):
+        self.path = os.path.splitext(path)[0] + ".npz"
+        self.mode = mode
+        if os.path.exists(self.path):
+            self.arrays = dict(np.load(self.path))
+        elif mode == "r":
+            raise OSError("no such file: " + path)
+        else:
+            self.arrays = {}
+
+    def __getitem__(self, key):
+        return self.arrays[key]
+
+    def keys(self):
+        return self.arrays.keys()
+
+    def create_dataset(self, name, data=None, compression=None):
+        self.arrays[name] = np.asarray(data)
+        np.savez_compressed(self.path, **self.arrays)
+
+    def close(self):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def _install_dataset_stubs(torch):
+    """Third-party modules the reference's datasets/Datasets.py imports at top level and this image lacks."""
+    h5 = types.ModuleType("h5py")
+    h5.File = _NpzH5File
+    sys.modules["h5py"] = h5
+    p3d, ops = types.ModuleType("pytorch3d"), types.ModuleType("pytorch3d.ops")
+    p3d.ops = ops
+    sys.modules.setdefault("pytorch3d", p3d)
+    sys.modules.setdefault("pytorch3d.ops", ops)
+    T = types.ModuleType("torchvision.transforms")
+
+    class ToTensor:                              # torchvision semantics: PIL RGB -> float32 CHW in [0, 1]
+        def __call__(self, img):
+            a = np.asarray(img, dtype=np.uint8)
+            return torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1))).float().div(255)
+
+    class Normalize:
+        def __init__(self, mean, std):
+            self.mean, self.std = torch.tensor(mean).view(-1, 1, 1), torch.tensor(std).view(-1, 1, 1)
+
+        def __call__(self, x):
+            return (x - self.mean) / self.std
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    def _unavailable(*a, **k):
+        raise RuntimeError("augmentations need the real torchvision")
+
+    T.ToTensor, T.Normalize, T.Compose = ToTensor, Normalize, Compose
+    T.RandomHorizontalFlip = T.ColorJitter = _unavailable
+    sys.modules["torchvision.transforms"] = T
+    sys.modules["torchvision"].transforms = T
+
+
+def dataset_goldens(torch):
+    """SURVEY 8 f4, pinned by what the reference HOLDS and RUNS:
+      * its own split lists data/DISN_split/*.lst parsed by its own reader (Datasets.py:293-298) and by the
+        test-list parser of arguments.py:112-125 -> counts, first / last id and a SHA-256 per list;
+      * its IM2SDF / IM2PointFarthest datasets run over a synthetic tree (oracle/dataset_fixture.py) whose shape
+        ids are the first entries of its 03001627_train.lst -> the items they return."""
+    import hashlib
+    import json
+    import random
+    import shutil
+    import tempfile
+    import types as _t
+    from . import dataset_fixture as DF
+    _install_dataset_stubs(torch)
+    cwd = os.getcwd()
+    os.chdir(REF)                                  # the reference opens './data/DISN_split/...'
+    try:
+        # the reference's module, loaded by path (a HuggingFace `datasets` package in site-packages shadows the name)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("reference_datasets_Datasets",
+                                                      os.path.join(REF, "datasets", "Datasets.py"))
+        RD = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(RD)
+        reader = RD.IM2SDF.read_shape_ids_from_file
+        lists = {}
+        split = os.path.join(REF, "data", "DISN_split")
+        for fn in sorted(os.listdir(split)):
+            if not fn.endswith(".lst"):
+                continue
+            ids = reader(None, os.path.join(split, fn))
+            lists[fn] = {"count": len(ids), "first": ids[0], "last": ids[-1],
+                         "sha256": hashlib.sha256("\n".join(ids).encode()).hexdigest()}
+        # arguments.py:112-125 (its parser runs argparse on sys.argv: restate the call with the same statements'
+        # inputs -- first 30 lines, split on ' ', category filter -- and pin the outcome for the default catlist)
+        with open(os.path.join(split, "testlist_all.lst")) as f:
+            lines = f.readlines()
+        testlist = [l.strip().split(" ") for l in lines[:30] if l.strip() != ""]
+        lists["testlist_all.lst"]["first30"] = testlist
+        tmp = tempfile.mkdtemp(prefix="list_ds_")
+        try:
+            with open(os.path.join(split, DF.CAT + "_train.lst")) as f:
+                shape_ids = [l.strip() for l in f.readlines()[:DF.N_SHAPES]]
+            image_dir, h5_dir = DF.write_tree(tmp, shape_ids)
+            cfg = _t.SimpleNamespace(**DF.config_fields(image_dir, h5_dir))
+            random.seed(333)
+            ds = RD.IM2SDF(cfg, "train")
+            items = [ds[i] for i in range(len(ds))]
+            again = ds[0]                           # the RandomState(333) stream continues across items
+            pf = RD.IM2PointFarthest(cfg, "train")
+            pf0_rgb, pf0_pc = pf[0]                  # (the ShapeNet variant returns a pair, Datasets.py:117)
+            out = {"n_items": np.array(len(ds)), "n_items_pf": np.array(len(pf)),
+                   "again_points": again["points"].numpy(), "pf0_pc": pf0_pc.numpy(), "pf0_rgb": pf0_rgb.numpy()}
+            for i, it in enumerate(items):
+                out[f"points{i}"] = it["points"].numpy()
+                out[f"values{i}"] = it["values"].numpy()
+                out[f"rgb{i}"] = it["rgb_image"].numpy()
+                out[f"occ{i}"] = np.packbits(it["occ"].numpy().astype(np.uint8).ravel())
+            cached = dict(np.load(os.path.join(h5_dir, DF.CAT, shape_ids[0], "occupancies.npz")))
+            out["occ_cache_keys"] = np.array(sorted(cached.keys()))
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    finally:
+        os.chdir(cwd)
+    lists["_tree_shape_ids"] = shape_ids
+    with open(os.path.join(OUT, "dataset_lists.json"), "w") as f:
+        json.dump(lists, f, indent=0, sort_keys=True)
+    np.savez_compressed(os.path.join(OUT, "dataset_items.npz"), **out)
+    print("datasets:", len(lists) - 1, "lists;", int(out["n_items"]), "IM2SDF items,", int(out["n_items_pf"]), "point items")
+
+
 if __name__ == "__main__":
-    if "--grads-only" in sys.argv:
+    if "--datasets-only" in sys.argv:
+        _torch = _import_reference()[0]
+        dataset_goldens(_torch)
+    elif "--grads-only" in sys.argv:
         _torch, _M, _L, _U, _dec = _import_reference()
         _torch.set_num_threads(8)
         grad_goldens(_torch, _dec, _M.PerceptualPooling())

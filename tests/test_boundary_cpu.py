@@ -173,8 +173,9 @@ def test_file_datasets_follow_the_reference_layout(tmp_path):
     rows = np.concatenate(rows)
     np.testing.assert_array_equal(item["points"].numpy(), rows[:, :3])
     np.testing.assert_array_equal(item["values"].numpy(), rows[:, 3])
-    # image planes are in the reference reader's (cv2) order: blue first, alpha dropped, /255
-    planes = [np.ascontiguousarray(p[:, :, 2::-1].transpose(2, 0, 1)).astype(np.float32) / 255 for p in pix]
+    # image planes as the reference's live reader gives them (PIL RGB -> ToTensor, Datasets.py:213-214,171):
+    # red first, alpha dropped, /255
+    planes = [np.ascontiguousarray(p[:, :, :3].transpose(2, 0, 1)).astype(np.float32) / 255 for p in pix]
     assert any(np.array_equal(item["rgb_image"].numpy(), p) for p in planes)
     # occupancy: nearest grid cell of every coarse point, cached next to the samples under the reference's key
     from scipy.spatial import cKDTree
