@@ -192,6 +192,10 @@ int list_prep_vox_maps(const ListMap3D maps[LIST_N_VOX_LEVELS], int32_t B, int32
     return fail(LIST_ERR_WORKSPACE, "pack buffer too small: %zu < %zu", pack_bytes, need);
   if (need > 0 && !aligned16(pack)) return fail(LIST_ERR_SHAPE, "pack must be 16-byte aligned");
   size_t off = 0;
+  ListMap3D fused_maps[LIST_N_VOX_LEVELS];
+  void* fused_out[LIST_N_VOX_LEVELS];
+  int fused_f16[LIST_N_VOX_LEVELS];
+  int n_fused = 0;
   for (int l = 0; l < LIST_N_VOX_LEVELS; ++l) {
     const ListMap3D& m = maps[l];
     if (!m.data || m.C < 1 || m.D < 1 || m.H < 1 || m.W < 1)
@@ -201,13 +205,24 @@ int list_prep_vox_maps(const ListMap3D maps[LIST_N_VOX_LEVELS], int32_t B, int32
     if (vox_in_place(m, &levels_out[l], map_dtype)) continue;
     const bool f16 = level_as_f16(m, map_dtype);
     void* dst = (char*)pack + off;
-    hipError_t e = launch_transpose_vox(m, B, f16, dst, (hipStream_t)stream);
-    if (e != hipSuccess) return hip_fail(e, "transpose_vox launch");
+#ifndef LIST_TRANSPOSE_NO_FUSE
+    if (transpose_tile_eligible(m, dst)) {           // launched together below
+      fused_maps[n_fused] = m; fused_out[n_fused] = dst; fused_f16[n_fused] = f16 ? 1 : 0; ++n_fused;
+    } else
+#endif
+    {
+      hipError_t e = launch_transpose_vox(m, B, f16, dst, (hipStream_t)stream);
+      if (e != hipSuccess) return hip_fail(e, "transpose_vox launch");
+    }
     levels_out[l].data = dst;
     levels_out[l].C = m.C; levels_out[l].D = m.D; levels_out[l].H = m.H; levels_out[l].W = m.W;
     levels_out[l].dtype = f16 ? LIST_MAP_F16 : LIST_MAP_F32; levels_out[l].reserved_ = 0;
     levels_out[l].image_stride = (int64_t)m.C * m.D * m.H * m.W;
     off += align_up((size_t)B * m.C * m.D * m.H * m.W * (f16 ? 2 : 4), 256);
+  }
+  if (n_fused > 0) {
+    hipError_t e = launch_transpose_vox_fused(fused_maps, fused_out, fused_f16, n_fused, B, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "transpose_vox launch");
   }
   return LIST_OK;
 }

@@ -361,6 +361,10 @@ struct GemmTnParams {
 hipError_t launch_prep_img(const ListMap2D maps[LIST_N_IMG_LEVELS], int B, int map_size, int Ct,
                            int f16, void* out, hipStream_t s);
 hipError_t launch_transpose_vox(const ListMap3D& m, int B, int f16, void* out, hipStream_t s);
+// the levels for which transpose_tile_eligible() holds, all in one launch
+bool transpose_tile_eligible(const ListMap3D& m, const void* out);
+hipError_t launch_transpose_vox_fused(const ListMap3D* maps, void* const* outs, const int* f16, int n, int B,
+                                      hipStream_t s);
 hipError_t launch_prep_weights(const ListMlpWeights& w, const FeatLayout& L, const PackedMlp& P,
                                char* packed, hipStream_t s);
 hipError_t launch_split(const float* x, unsigned short* hi, unsigned short* lo, int64_t n, int fmt,

@@ -247,24 +247,42 @@ static bool try_prep_img_nhwc(const ListMap2D& m, int B, int ms, int Ct, int cof
 // slots on arithmetic and index math than the 16-B store it feeds can hide).  No LDS: the 8 lanes of a
 // pixel read 8-channel groups of the same two taps (L1/L2 hits), and write one full 128-B line (fp16:
 // 64 channels; fp32: 256 B) per pixel, 8 pixels per wave-instruction.  Same bits as k_prep_img.
-constexpr int kRowsPx = 16;                 // output columns per workgroup (x 8 channel octets = 128 threads)
+#ifndef LIST_PREP_RY
+#define LIST_PREP_RY 16
+#endif
+#ifndef LIST_PREP_RY_MAX
+#define LIST_PREP_RY_MAX 32
+#endif
+#ifndef LIST_PREP_PX
+#define LIST_PREP_PX 16
+#endif
+#ifndef LIST_PREP_THREADS
+#define LIST_PREP_THREADS (LIST_PREP_PX * 8)
+#endif
+constexpr int kRowsPx = LIST_PREP_PX;                 // output columns per workgroup (x 8 channel octets = 128 threads)
 constexpr int kRowsCg = 64;                 // channels per workgroup
-struct PrepRowsLevel { ListMap2D m; int coff, wg_begin, cgroups, vec; };
-struct PrepRowsArgs { PrepRowsLevel lv[LIST_N_IMG_LEVELS]; int n_levels, B, ms, Ct, nxt, nyt, RY; };
+struct PrepRowsLevel { ListMap2D m; int coff, wg_begin, cgroups, vec, RY, nyt; };
+struct PrepRowsArgs { PrepRowsLevel lv[LIST_N_IMG_LEVELS]; int n_levels, B, ms, Ct, nxt; };
 
 template <int F16>
-__global__ __launch_bounds__(128) void k_prep_img_rows(PrepRowsArgs a, void* __restrict__ out) {
+__global__ __launch_bounds__(LIST_PREP_THREADS) void k_prep_img_rows(PrepRowsArgs a, void* __restrict__ out) {
+  // level-major block order: consecutive workgroups are x tiles of one (level, channel group, row block), 32 KB
+  // apart in the output.  (Pixel-tile-major -- the 16 channel groups of a pixel tile side by side, so that a
+  // pixel's 2 KB leave together -- measured 0.73 ms instead of 0.19: the writes of a moment then fall on few
+  // memory channels.)
   int l = 0;
 #pragma unroll
   for (int i = 1; i < LIST_N_IMG_LEVELS; ++i)
     if (i < a.n_levels && (int)blockIdx.x >= a.lv[i].wg_begin) l = i;
-  const ListMap2D m = a.lv[l].m;
-  const int coff = a.lv[l].coff, cgroups = a.lv[l].cgroups, vec = a.lv[l].vec;
+  const int cgroups = a.lv[l].cgroups;
   int idx = blockIdx.x - a.lv[l].wg_begin;
   const int xt = idx % a.nxt; idx /= a.nxt;
   const int cg = idx % cgroups; idx /= cgroups;
-  const int yt = idx % a.nyt;
-  const int b = idx / a.nyt;
+  const int yt = idx % a.lv[l].nyt;
+  const int b = idx / a.lv[l].nyt;
+  const int RY = a.lv[l].RY;
+  const ListMap2D m = a.lv[l].m;
+  const int coff = a.lv[l].coff, vec = a.lv[l].vec;
   const int ms = a.ms;
   const int q = threadIdx.x & 7, xi = threadIdx.x >> 3;
   const int xo = xt * kRowsPx + xi;
@@ -281,6 +299,11 @@ __global__ __launch_bounds__(128) void k_prep_img_rows(PrepRowsArgs a, void* __r
   const float* p0 = m.data + (int64_t)b * m.sb + (int64_t)c * m.sc + (int64_t)x0 * m.sw;
   const float* p1 = m.data + (int64_t)b * m.sb + (int64_t)c * m.sc + (int64_t)x1 * m.sw;
 
+  // (Tried: fetching the source-row segment of the tile with loads that run along x and turning it through LDS
+  // into [column][64 channels] -- 0.29 ms instead of 0.19: two barriers and an LDS round trip per fetch lengthen
+  // the chain of dependent fetches that bounds a workgroup.  Pixel-tile-major block order: 0.73 ms.  One workgroup
+  // per 8 columns x all 1024 channels (16 KB contiguous per row): 0.22 ms.  Non-temporal stores, 8/16/32 columns
+  // or rows per workgroup: within 3 %.)
   auto hrow = [&](int r, float (&h)[8]) {
     const float* r0 = p0 + (int64_t)r * m.sh;
     const float* r1 = p1 + (int64_t)r * m.sh;
@@ -298,7 +321,7 @@ __global__ __launch_bounds__(128) void k_prep_img_rows(PrepRowsArgs a, void* __r
     for (int k = 0; k < 8; ++k) h[k] = u[k] * wx0 + v[k] * wx1;
   };
 
-  const int y_first = yt * a.RY, y_end = min(y_first + a.RY, ms);
+  const int y_first = yt * RY, y_end = min(y_first + RY, ms);
   float top[8], bot[8];
   int row_top = -1, row_bot = -1;
   int64_t oi = ((int64_t)(b * ms + y_first) * ms + xo) * a.Ct + coff + c;
@@ -334,7 +357,13 @@ __global__ __launch_bounds__(128) void k_prep_img_rows(PrepRowsArgs a, void* __r
     if (F16) {
       const uint2 lo = half4(make_float4(o[0], o[1], o[2], o[3]));
       const uint2 hi = half4(make_float4(o[4], o[5], o[6], o[7]));
+#ifndef LIST_PREP_NO_NT          // streamed once, read again only by the 2-D gather: keep it out of the L2 working set
+      __builtin_nontemporal_store((f32x4){__builtin_bit_cast(float, lo.x), __builtin_bit_cast(float, lo.y),
+                                          __builtin_bit_cast(float, hi.x), __builtin_bit_cast(float, hi.y)},
+                                  (f32x4*)((unsigned short*)out + oi));
+#else
       *(uint4*)((unsigned short*)out + oi) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#endif
     } else {
       *(float4*)((float*)out + oi) = make_float4(o[0], o[1], o[2], o[3]);
       *(float4*)((float*)out + oi + 4) = make_float4(o[4], o[5], o[6], o[7]);
@@ -352,8 +381,8 @@ hipError_t launch_prep_img(const ListMap2D maps[LIST_N_IMG_LEVELS], int B, int m
 #ifndef LIST_PREP_IMG_NO_ROWS
   {
     PrepRowsArgs a;
-    a.n_levels = 0; a.B = B; a.ms = map_size; a.Ct = Ct; a.RY = 16;
-    a.nxt = (map_size + kRowsPx - 1) / kRowsPx; a.nyt = (map_size + a.RY - 1) / a.RY;
+    a.n_levels = 0; a.B = B; a.ms = map_size; a.Ct = Ct;
+    a.nxt = (map_size + kRowsPx - 1) / kRowsPx;
     int64_t wgs = 0;
     bool all = true;
     int co = 0;
@@ -362,16 +391,38 @@ hipError_t launch_prep_img(const ListMap2D maps[LIST_N_IMG_LEVELS], int B, int m
       if (!rows_eligible(m, map_size, Ct, co)) { all = false; break; }
       PrepRowsLevel& lv = a.lv[a.n_levels++];
       lv.m = m; lv.coff = co; lv.wg_begin = (int)wgs; lv.cgroups = m.C / kRowsCg;
+      // Output rows per workgroup.  A thread's rows form a chain of dependent source-row fetches (~2 us each):
+      // about five fetches per workgroup everywhere -- few rows where every output row needs new source rows
+      // (down-sampling: 2 per row), many where ten output rows share one (the 14 px level)
+      {
+        const float sy = (float)(m.H - 1) / (float)(map_size - 1);
+        int ry = (int)(3.3f / (sy > 0.05f ? sy : 0.05f) + 0.5f);
+#ifdef LIST_PREP_RY_UNIFORM
+        ry = LIST_PREP_RY;
+#endif
+        lv.RY = ry < 2 ? 2 : (ry > LIST_PREP_RY_MAX ? LIST_PREP_RY_MAX : ry);
+        lv.nyt = (map_size + lv.RY - 1) / lv.RY;
+      }
       lv.vec = (m.sc == 1 && (m.sw % 4) == 0 && (m.sh % 4) == 0 && (m.sb % 4) == 0 &&
                 (reinterpret_cast<uintptr_t>(m.data) & 15) == 0) ? 1 : 0;
-      wgs += (int64_t)B * a.nyt * lv.cgroups * a.nxt;
+      wgs += (int64_t)B * lv.nyt * lv.cgroups * a.nxt;
       co += m.C;
     }
     if (all && wgs > 0 && wgs < 2147483647LL) {
+#ifdef LIST_PREP_PER_LEVEL           // profiling only: one launch per level, so that a kernel trace shows each
+      for (int i = 0; i < a.n_levels; ++i) {
+        PrepRowsArgs one = a;
+        one.n_levels = 1; one.lv[0] = a.lv[i]; one.lv[0].wg_begin = 0;
+        const unsigned n = (unsigned)((int64_t)B * a.lv[i].nyt * a.lv[i].cgroups * a.nxt);
+        if (f16) hipLaunchKernelGGL(k_prep_img_rows<1>, dim3(n), dim3(kRowsPx * 8), 0, s, one, out);
+        else hipLaunchKernelGGL(k_prep_img_rows<0>, dim3(n), dim3(kRowsPx * 8), 0, s, one, out);
+      }
+      return hipGetLastError();
+#endif
       if (f16)
-        hipLaunchKernelGGL(k_prep_img_rows<1>, dim3((unsigned)wgs), dim3(128), 0, s, a, out);
+        hipLaunchKernelGGL(k_prep_img_rows<1>, dim3((unsigned)wgs), dim3(kRowsPx * 8), 0, s, a, out);
       else
-        hipLaunchKernelGGL(k_prep_img_rows<0>, dim3((unsigned)wgs), dim3(128), 0, s, a, out);
+        hipLaunchKernelGGL(k_prep_img_rows<0>, dim3((unsigned)wgs), dim3(kRowsPx * 8), 0, s, a, out);
       return hipGetLastError();
     }
   }
@@ -436,14 +487,12 @@ __global__ __launch_bounds__(256) void k_transpose_vox(ListMap3D m, int c_begin,
 // ((v>>2)&7)<<2 (a bijection inside each group of 4 voxels) so that the transposing ds_write_b32
 // pattern spreads over 8 bank groups and the ds_read_b128 of 4 channels stays 16-B aligned.
 template <int C, int F16>
-__global__ __launch_bounds__(256) void k_transpose_vox_tile(const float* __restrict__ src, int64_t sb,
-                                                            int64_t sc, int nvox,
-                                                            void* __restrict__ out) {
+__device__ __forceinline__ void transpose_vox_tile(const float* __restrict__ src, int64_t sb, int64_t sc, int nvox,
+                                                   void* __restrict__ out, float* __restrict__ tile, int tile_x,
+                                                   int b) {
   constexpr int V = 8192 / C;          // voxels per tile
   constexpr int V4 = V / 4;
-  __shared__ __attribute__((aligned(16))) float tile[8192];
-  const int b = blockIdx.y;
-  const int v0 = blockIdx.x * V;
+  const int v0 = tile_x * V;
   const float* in = src + (int64_t)b * sb + v0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -487,6 +536,66 @@ __global__ __launch_bounds__(256) void k_transpose_vox_tile(const float* __restr
                                   (f32x4*)((float*)out + dst + a));
     }
   }
+}
+
+template <int C, int F16>
+__global__ __launch_bounds__(256) void k_transpose_vox_tile(const float* __restrict__ src, int64_t sb,
+                                                            int64_t sc, int nvox,
+                                                            void* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float tile[8192];
+  transpose_vox_tile<C, F16>(src, sb, sc, nvox, out, tile, blockIdx.x, blockIdx.y);
+}
+
+// All levels that take the tile path in ONE launch (the five hand-offs of a step are independent: one grid fills
+// the tails of the small levels with the big one's tiles and drops four dependent-launch gaps).
+struct TransposeJob { const float* src; void* out; int64_t sb, sc; int nvox, C, f16, tiles_x, wg_begin; };
+struct TransposeJobs { TransposeJob j[LIST_N_VOX_LEVELS]; int n; int B; };
+
+__global__ __launch_bounds__(256) void k_transpose_vox_fused(TransposeJobs a) {
+  __shared__ __attribute__((aligned(16))) float tile[8192];
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < LIST_N_VOX_LEVELS; ++i)
+    if (i < a.n && (int)blockIdx.x >= a.j[i].wg_begin) l = i;
+  const TransposeJob j = a.j[l];
+  const int idx = blockIdx.x - j.wg_begin;
+  const int tx = idx % j.tiles_x, b = idx / j.tiles_x;
+#define LIST_TR_CASE(CC)                                                                          \
+  case CC:                                                                                        \
+    if (j.f16) transpose_vox_tile<CC, 1>(j.src, j.sb, j.sc, j.nvox, j.out, tile, tx, b);          \
+    else transpose_vox_tile<CC, 0>(j.src, j.sb, j.sc, j.nvox, j.out, tile, tx, b);                \
+    break;
+  switch (j.C) {
+    LIST_TR_CASE(16) LIST_TR_CASE(32) LIST_TR_CASE(64) LIST_TR_CASE(128)
+    default: break;
+  }
+#undef LIST_TR_CASE
+}
+
+bool transpose_tile_eligible(const ListMap3D& m, const void* out) {
+  const int nvox = m.D * m.H * m.W;
+  const bool spatial_contig = m.sw == 1 && m.sh == m.W && m.sd == (int64_t)m.H * m.W;
+  const bool aligned = (reinterpret_cast<uintptr_t>(m.data) & 15) == 0 && (m.sb % 4) == 0 &&
+                       (m.sc % 4) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+  return m.dtype == LIST_MAP_F32 && spatial_contig && aligned &&
+         (m.C == 16 || m.C == 32 || m.C == 64 || m.C == 128) && nvox % (8192 / m.C) == 0;
+}
+
+hipError_t launch_transpose_vox_fused(const ListMap3D* maps, void* const* outs, const int* f16, int n, int B,
+                                      hipStream_t s) {
+  TransposeJobs a;
+  a.n = 0; a.B = B;
+  int64_t wgs = 0;
+  for (int i = 0; i < n; ++i) {
+    const ListMap3D& m = maps[i];
+    TransposeJob& j = a.j[a.n++];
+    j.src = (const float*)m.data; j.out = outs[i]; j.sb = m.sb; j.sc = m.sc; j.nvox = m.D * m.H * m.W; j.C = m.C;
+    j.f16 = f16[i]; j.tiles_x = j.nvox / (8192 / m.C); j.wg_begin = (int)wgs;
+    wgs += (int64_t)j.tiles_x * B;
+  }
+  if (wgs <= 0 || wgs >= 2147483647LL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_transpose_vox_fused, dim3((unsigned)wgs), dim3(256), 0, s, a);
+  return hipGetLastError();
 }
 
 template <int C>
