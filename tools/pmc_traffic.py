@@ -41,7 +41,9 @@ def kernel_key(name, grid, seq):
         return "gather_vox_" + lvl
     return {"k_gather_img": "gather_img", "k_gather_tail": "gather_tail",
             "k_transpose_vox_tile": "prep_vox_ndhwc", "k_transpose_vox": "prep_vox_ndhwc",
+            "k_transpose_vox_fused": "prep_vox_ndhwc_fused", "k_prep_img_rows": "prep_img_resize_nhwc_rows",
             "k_prep_img_tile": "prep_img_resize_nhwc", "k_prep_img": "prep_img_resize_nhwc",
+            "k_gather_fixup": "exact_redo",
             "k_sort_hist": "sort_points", "k_sort_scan": "sort_points", "k_sort_scatter": "sort_points"}.get(k)
 
 
@@ -52,9 +54,15 @@ def collect(d, counter):
         rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
         rows.sort(key=lambda r: int(r["Dispatch_Id"]))
         for r in rows:
-            key = kernel_key(r["Kernel_Name"], int(r.get("Grid_Size", 0) or 0), seq)
+            key = kernel_key(r["Kernel_Name"], int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0), seq)
             if key:
                 per[key].append(float(r["Counter_Value"]))
+    # every fc_0 launch is followed by a GATED re-run of the same kernel (exact border semantics) that exits at
+    # once on finite inputs: keep the launches that moved data
+    for key, vals in per.items():
+        if key.startswith("fc_") and vals:
+            top = max(vals)
+            per[key] = [v for v in vals if v > 0.05 * top] or vals
     return per
 
 
@@ -63,6 +71,12 @@ def main():
     out = sys.argv[4] if len(sys.argv) > 4 else "profiles/pmc_traffic.json"
     fetch, write = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
     groups = {"prep_vox_ndhwc": 5, "prep_img_resize_nhwc": 5, "sort_points": 3}   # launches per step
+    # round 2: the resize and the voxel hand-offs are ONE launch each; report them under the names bench.py uses
+    for table in (fetch, write):
+        for new, old in (("prep_vox_ndhwc_fused", "prep_vox_ndhwc"), ("prep_img_resize_nhwc_rows", "prep_img_resize_nhwc")):
+            if new in table:
+                table[old] = table.pop(new)
+                groups[old] = 1
     res = {}
     for k in sorted(set(fetch) | set(write)):
         n = groups.get(k, 1)

@@ -4,7 +4,7 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 python learning-implicitly-from-spatial-transformers-network_amd/build.py --force > /dev/null 2>&1
 timeout -k 10 300 python -m pytest tests/test_hip_parity.py -m gpu -x -q -k "prep or fused or percep or odd" 2>&1 | tail -3
-timeout -k 10 1000 bash tools/ab_build.sh "" "-DLIST_PREP_RY_UNIFORM" "-DLIST_PREP_RY_MAX=16" "-DLIST_PREP_NT" > gpurun_out/r2_ab8.log 2>&1
+timeout -k 10 1000 bash tools/ab_build.sh "" "-DLIST_PREP_NO_XCD" > gpurun_out/r2_ab8.log 2>&1
 python - <<'PY'
 import re
 for line in open("gpurun_out/r2_ab8.log"):
