@@ -272,9 +272,12 @@ __global__ __launch_bounds__(256) void k_gather_vox_near(GatherParams g, ListVox
     const float wxz[4] = {wcx[1] * wcz[1], wcx[2] * wcz[1], wcx[1] * wcz[2], wcx[2] * wcz[2]};
     const float wxy[4] = {wcx[1] * wcy[1], wcx[2] * wcy[1], wcx[1] * wcy[2], wcx[2] * wcy[2]};
 
-    // (Tried: three passes of 16 taps -- x, y, z axis, the 8 centre taps fetched three times -- for 168 instead of
-    // 218 registers, i.e. 3 instead of 2 waves per SIMD: 0.143 instead of 0.130 ms.  The kernel follows its tap
-    // loads through the L1, not its occupancy.)
+    // (Tried, round 2: three passes of 16 taps -- x, y, z axis, the 8 centre taps fetched three times -- for 168
+    // instead of 218 registers, i.e. 3 instead of 2 waves per SIMD: 0.143 instead of 0.130 ms.  And the union of the
+    // workgroup's 4^3 windows copied once into LDS, every tap a ds_read_b128: taken by 84 % of the workgroups of the
+    // 8^3 level (median box 108 voxels = 27 KB), 0.130 ms either way.  Neither occupancy nor where the taps come
+    // from moves this kernel: at ~1460 vector instructions per 4 points and 2 waves per SIMD it is bound by
+    // vector-instruction issue.)
     // 4 x-planes x centre (y,z) 2x2: A[k][0..3] = (z1,y1) (z1,y2) (z2,y1) (z2,y2) of x-plane k
     Raw A[4][4];
 #pragma unroll
