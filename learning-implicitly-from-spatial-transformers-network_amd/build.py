@@ -18,12 +18,26 @@ OBJ_DIR = os.path.join(CSRC, "_obj")
 ARCH = "gfx950"
 
 
+STAMP = LIB + ".stamp"
+
+
+def _fingerprint():
+    """SHA-256 over every source, header and the compile flags: what the library was built FROM, independent of
+    file times (a checkout or a copy to the GPU box resets those)."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update((ARCH + "|" + os.environ.get("LIST_HIPCC_FLAGS", "")).encode())
+    for d in [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.join(INCLUDE, "list_hip.h")]:
+        with open(d, "rb") as f:
+            h.update(os.path.basename(d).encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
 def _stale():
-    if not os.path.exists(LIB):
+    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.join(INCLUDE, "list_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as f:
+        return f.read().strip() != _fingerprint()
 
 
 def build(force=False, verbose=False):
@@ -66,6 +80,9 @@ def build(force=False, verbose=False):
             if os.path.exists(o):
                 os.remove(o)
     os.replace(tmp, LIB)            # atomic: concurrent readers never see a half-written library
+    with open(STAMP + f".tmp{os.getpid()}", "w") as f:
+        f.write(_fingerprint() + "\n")
+    os.replace(STAMP + f".tmp{os.getpid()}", STAMP)
     return LIB
 
 
