@@ -542,27 +542,16 @@ def sdf_query_backward(ctx, grad_sdf, packed_bwd, want_mlp=True, want_img=True, 
     if overlap:        # dW0 | atomic scatters | window scatters | gathers run side by side (joined before return)
         with _AuxStreams(dev) as (a0, a1), torch.cuda.device(dev):
             ga.aux_streams[0], ga.aux_streams[1] = a0.cuda_stream, a1.cuda_stream
+            # The library joins both side streams back into the caller's stream before it returns -- on success AND
+            # on every error path -- so whatever runs on the caller's stream afterwards (including the caching
+            # allocator handing these buffers to a later allocation on that stream) is ordered behind the side
+            # work.  No Tensor.record_stream here: it would park the 4 GB of workspace / gradient buffers behind
+            # side-stream events and make every step allocate afresh (measured: training step 8 -> 18 ms).
             _check(lib.list_sdf_query_bwd(C.byref(ga), _stream()), "list_sdf_query_bwd")
-            # every buffer of this call (ws, the outputs) was also used on the side streams
-            for t in [ws, g] + _tensors_of(out):
-                t.record_stream(a0)
-                t.record_stream(a1)
         return out
     with torch.cuda.device(dev):
         _check(lib.list_sdf_query_bwd(C.byref(ga), _stream()), "list_sdf_query_bwd")
     return out
-
-
-def _tensors_of(out):
-    ts = []
-    for v in out.values():
-        if torch.is_tensor(v):
-            ts.append(v)
-        elif isinstance(v, dict):
-            ts += list(v.values())
-        else:
-            ts += list(v)
-    return ts
 
 
 def _level_descriptors(like, img_C):

@@ -17,4 +17,4 @@ except Exception as e:
     print(sys.argv[1], "unreadable", e)
 PY
 done
-tail -3 gpurun_out/${T}_bench_*.err
+for f in gpurun_out/${T}_bench_*.err; do tail -n 2 "$f"; done
