@@ -363,8 +363,23 @@ __global__ __launch_bounds__(LIST_PREP_THREADS) void k_prep_img_rows(PrepRowsArg
     for (int k = 0; k < 8; ++k) o[k] = top[k] * wy0 + bot[k] * wy1;
     if (!active) continue;
     if (F16) {
+#ifndef LIST_PREP_SAT_ALWAYS
+      // saturate only the rows that need it: one compare per value (|x| is a free source modifier; a NaN compares
+      // false and converts to NaN, +-inf compares true) instead of the 3-instruction NaN-preserving clamp per value
+      // -- the kernel is bound by vector issue and the clamp was a third of its steady-state row
+      bool over = false;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) over = over || (fabsf(o[k]) > 65504.f);
+      if (over) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = sat_h(o[k]);
+      }
+      const uint2 lo = half4_inrange(make_float4(o[0], o[1], o[2], o[3]));
+      const uint2 hi = half4_inrange(make_float4(o[4], o[5], o[6], o[7]));
+#else
       const uint2 lo = half4(make_float4(o[0], o[1], o[2], o[3]));
       const uint2 hi = half4(make_float4(o[4], o[5], o[6], o[7]));
+#endif
 #ifndef LIST_PREP_NO_NT          // streamed once, read again only by the 2-D gather: keep it out of the L2 working set
       __builtin_nontemporal_store((f32x4){__builtin_bit_cast(float, lo.x), __builtin_bit_cast(float, lo.y),
                                           __builtin_bit_cast(float, hi.x), __builtin_bit_cast(float, hi.y)},
