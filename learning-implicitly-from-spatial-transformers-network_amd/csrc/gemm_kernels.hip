@@ -53,6 +53,9 @@ template <int TERMS> struct Pipe {
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
+#ifdef LIST_GEMM_NO_VMWAIT   // ablation (wrong results): loads are issued but their landing is never waited for
+  if (N != 0) return;
+#endif
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
@@ -380,18 +383,154 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(GemmParams p) {
   gemm_epilogue<EPI, FP16>(p, acc, smem, m0, n0, wm, wn, wave, lane);
 }
 
+// ---- the 16x16x32 MFMA shape ----------------------------------------------------------------------------------
+// Identical tiling, staging and pipeline; the wave's 128x64 outputs are 8x4 tiles of 16x16 (4 accumulator
+// registers each).  Operand lane map: lane l holds A[row l&15][k = 8*(l>>4) .. +7] of a 16x32 block; C/D:
+// col = lane&15, row = 4*(lane>>4) + reg.  MI355X holds a higher clock on this shape under sustained MFMA load
+// (fc_0, same schedule, same box: 1.98 GHz and 968 k cycles against 1.84 GHz and 1003 k cycles on 32x32x16).
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+
+template <int FP16>
+__device__ __forceinline__ f32x4v mfma16(const bf16x8& a, const bf16x8& b, const f32x4v& c) {
+  if (FP16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b),
+                                                  c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// staged epilogue of the 16x16 accumulator layout: 32 rows (two 16-row tiles) x 64 columns per turn; the 64
+// lanes of every ds_write_b32 hit 64 distinct banks (row stride 68 floats: +4 rows = +16 banks)
+template <typename F>
+__device__ __forceinline__ void staged_epilogue16(const f32x4v (&acc)[8][4], char* smem, int wave, int lane,
+                                                  F&& emit) {
+  float* tile = (float*)smem + wave * (32 * kStageLd);
+  const int col_in = lane & 15, row_in = 4 * (lane >> 4);
+  const int rr = lane >> 3, c8 = (lane & 7) * 8;
+  __syncthreads();                                 // every wave is done with the operand stages
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          tile[(ii * 16 + row_in + e) * kStageLd + j * 16 + col_in] = acc[2 * c + ii][j][e];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = rr + 8 * k;
+      const float4 a = *(const float4*)(tile + r * kStageLd + c8);
+      const float4 b = *(const float4*)(tile + r * kStageLd + c8 + 4);
+      const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      emit(c * 32 + r, c8, v);
+    }
+    __syncthreads();
+  }
+}
+
+// epilogues of the 16x16 kernels: hidden layer (bias + ReLU + 16-bit planes, NaN probe), fp32 (diagnostic),
+// fused fc_2 + fc_out
+template <int EPI, int FP16>
+__device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4v (&acc)[8][4], char* smem, int m0, int n0,
+                                                int wm, int wn, int wave, int lane) {
+  const int col_in = lane & 15, row_in = 4 * (lane >> 4);
+  if (EPI == EPI_RELU_SPLIT) {
+    const int64_t row_base = m0 + wm * 128;
+    const int col_base = n0 + wn * 64;
+    bool bad = false;
+    staged_epilogue16(acc, smem, wave, lane, [&](int r, int c8, const float (&v)[8]) {
+      float o[8];
+      const float4 b0 = p.bias ? *(const float4*)(p.bias + col_base + c8) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 b1 = p.bias ? *(const float4*)(p.bias + col_base + c8 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { o[e] = relu_nan(v[e] + bb[e]); bad = bad || (o[e] != o[e]); }
+      store8_planes<FP16>(p.out_hi, p.out_lo, (row_base + r) * p.ldo + col_base + c8, o);
+    });
+    // NaN probe for the exact redo of the row tile's gathers (see gemm_epilogue)
+    if (p.nan_tiles && __builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) p.nan_tiles[m0 / BM] = 1;
+  } else if (EPI == EPI_F32) {
+    const int64_t lane_off = (int64_t)(m0 + wm * 128 + row_in) * p.N + n0 + wn * 64 + col_in;
+    float* of = p.out_f32 + lane_off;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float bias = p.bias ? p.bias[n0 + wn * 64 + j * 16 + col_in] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[i][j][e] + bias;
+          if (p.relu) v = relu_nan(v);
+          of[(i * 16 + e) * p.N + j * 16] = v;
+        }
+    }
+  } else {
+    float part[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) part[i][e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = wn * 64 + j * 16 + col_in;      // n0 == 0 (N == BN)
+      const float bias = p.bias[col], w3 = p.w3[col];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[i][e] += relu_nan(acc[i][j][e] + bias) * w3;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = part[i][e];
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 1);
+        part[i][e] = v;
+      }
+    __syncthreads();
+    float* red = (float*)smem;                         // [4 (wn)][256 rows]
+    if (col_in == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wn * 256 + wm * 128 + i * 16 + row_in + e] = part[i][e];
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+      const int row = m0 + threadIdx.x;
+      if (row < p.n_valid) {
+        const int rl = threadIdx.x;
+        p.sdf[p.order ? p.order[row] : row] =
+            ((red[rl] + red[256 + rl]) + (red[512 + rl] + red[768 + rl])) + p.b3[0];
+      }
+    }
+  }
+}
+
 // ---- ping-pong schedule (single-plane operands, BK = 64) -----------------------------------------------------------
-// Same tile, LDS image, swizzle and epilogues as k_gemm_nt; a different schedule, after the guide's 256^2 8-phase
-// template.  A K-tile is four phases, one 64 x 32 quadrant of the wave's 128 x 64 outputs each (8 MFMAs over K = 64):
-//   p0: read A(i0,i1), W(j0) -> q(i01,j0)   p1: read W(j1) -> q(i01,j1)   p2: read A(i2,i3) -> q(i23,j1)   p3: -> q(i23,j0)
+// Same tile, LDS image, swizzle and epilogues as the plain loops; a different schedule, after the guide's 256^2 8-phase
+// template.  A K-tile is four phases, one 64 x 32 quadrant of the wave's 128 x 64 outputs each (over K = 64: 16 MFMAs
+// of 16x16x32, or 8 of 32x32x16 with -DLIST_PP_SHAPE32):
+//   p0: read A(first 64 rows), W(first 32 cols) -> q(0,0)   p1: read W(second) -> q(0,1)   p2: read A(second) -> q(1,1)
+//   p3: -> q(1,0)
 // Every phase is [READ: ds_reads + ONE quarter of the next K-tile's LDS-DMA staging | s_barrier | MFMAs | s_barrier],
 // and the two wave groups (wm = 0 / 1: the two waves of every SIMD) run ONE barrier apart, so that on each SIMD one
-// wave reads LDS and issues loads while the other issues MFMAs.  Staging runs kLead phases ahead of the phase that
-// owns the quarter (quarter g = 4 tile + {A first halves, W first halves, W second halves, A second halves} is issued
-// in phase g - kLead) and the wait is a counted vmcnt(2 (kLead - 2)) at the end of every READ section: the kLead - 2
-// youngest quarters stay in flight across the barriers, the loop never drains to 0.  (Measured: -2 .. -6 % against the
-// 2-stage loop depending on the device; kLead 4, 5 and 6 within 1 %: the loop is bound by LDS / LDS-DMA throughput,
-// not by load latency.)
+// wave reads LDS and issues loads while the other issues MFMAs.  The MFMA cluster is held between its two barriers
+// by an s_setprio pair and scheduling fences: without them hipcc moves MFMAs across the raw s_barrier (they touch
+// registers only) in among the next READ section and the groups stop alternating (round 2: fc_0 0.605 -> 0.567 ms).
+// Staging runs kLead phases ahead of the phase that owns the quarter (quarter g = 4 tile + {A first halves, W first
+// halves, W second halves, A second halves} is issued in phase g - kLead) and the wait is a counted
+// vmcnt(2 (kLead - 2)) at the end of every READ section: the kLead - 2 youngest quarters stay in flight across the
+// barriers, the loop never drains to 0.
+// What bounds it (round-2 ablations on fc_0, one box): MFMAs + barriers alone 0.42 ms (the pipe idles ~95
+// cycles per barrier interval), the LDS-DMA stream alone 0.42 ms (0.29 ms with A resident in L2), both 0.55 ms; never
+// waiting for the loads, or kLead 5 / 6, changes nothing: the per-CU rate of the vector-memory path (~57 cycles per
+// 1-KB piece with A from HBM) paces the loop, in shader cycles -- hence the 16x16x32 shape, on which the chip holds
+// 1.98 instead of 1.84 GHz: 0.55 -> 0.49 ms.
 // Ordering: every wave has waited for its loads of quarter g by phase g-2, the barrier behind the later group's
 // wait makes it complete for all, and it is first read in phase g-1 at the earliest (W first halves; A first g,
 // W second g-1, A second g-1).  The 8 quarter slots are the two K-tile buffers; a slot is re-staged two phases
@@ -403,8 +542,23 @@ __device__ __forceinline__ int w_quarter_row(int q, int half) { return (q >> 2) 
 #define LIST_PP_LEAD 4
 #endif
 constexpr int kLead = LIST_PP_LEAD;      // phases between the issue of a staging quarter and the phase that owns it (4..6)
+#ifdef LIST_PP_SHAPE32
+constexpr bool kPpShape16 = false;
+#else
+constexpr bool kPpShape16 = true;
+#endif
+template <int P> __device__ __forceinline__ void pp_prio() {
+#ifndef LIST_PP_NO_SETPRIO
+  __builtin_amdgcn_s_setprio(P);
+#endif
+}
+__device__ __forceinline__ void pp_fence() {
+#ifndef LIST_PP_NO_FENCE
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
 
-template <int EPI, int FP16>
+template <int EPI, int FP16, bool S16>
 __global__ __launch_bounds__(512, 2) void k_gemm_nt_pp(GemmParams p) {
   using P = Pipe<1>;
   static_assert(P::BK == 64 && P::kRowBytes == 128, "single-plane pipeline");
@@ -418,16 +572,24 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_pp(GemmParams p) {
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
   if (p.tile_gate && p.tile_gate[tile / tiles_n] == 0) return;      // gated re-run (exact border semantics): uniform exit
 
-  f32x16 acc[4][2];
+  // accumulators: 4x2 tiles of 32x32 (16 registers each) or 8x4 tiles of 16x16 (4 each); 128 registers either way
+  typedef typename std::conditional<S16, f32x4v, f32x16>::type acc_t;
+  constexpr int TI = S16 ? 8 : 4, TJ = S16 ? 4 : 2, TE = S16 ? 4 : 16;
+  acc_t acc[TI][TJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TJ; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < TE; ++e) acc[i][j][e] = 0.f;
 
-  const int frow = lane & 31, fh = lane >> 5;
-  const int fswz = P::swz(frow);
+  // operand blocks: 32 rows x 16 k (lane: row l&31, k-octet l>>5) or 16 rows x 32 k (row l&15, k-octet l>>4)
+  constexpr int TR = S16 ? 16 : 32;            // rows of an operand block
+  constexpr int KS = S16 ? 2 : 4;              // MFMA k-steps per K-tile
+  constexpr int KO = S16 ? 4 : 2;              // 16-B k-octets per MFMA k-step
+  constexpr int HA = 64 / TR, HW = 32 / TR;    // operand blocks per A half (64 rows) / W half (32 columns)
+  const int frow = lane & (TR - 1), fo = lane / TR;
+  const int fswz = P::swz(frow);               // block row offsets are multiples of 16
   const int a_row_off = (wm * 128 + frow) * P::kRowBytes;
   const int w_row_off = (wn * 64 + frow) * P::kRowBytes;
   const int64_t ld = (int64_t)p.K * 2;
@@ -446,8 +608,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_pp(GemmParams p) {
       glds16(g, sbase + (is_a ? 0 : P::kWOff) + row0 * P::kRowBytes);
     }
   };
-  auto frag = [&](const char* cur, int plane_off, int row_off, int t32, int s2) -> bf16x8 {
-    return *(const bf16x8*)(cur + plane_off + row_off + t32 * 32 * P::kRowBytes + (((2 * s2 + fh) ^ fswz) << 4));
+  auto frag = [&](const char* cur, int plane_off, int row_off, int blk, int ks) -> bf16x8 {
+    return *(const bf16x8*)(cur + plane_off + row_off + blk * TR * P::kRowBytes + (((KO * ks + fo) ^ fswz) << 4));
   };
 
   // prologue: quarters 0 .. kLead-1; the first K-tile must be complete for everybody; then the second wave
@@ -460,7 +622,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_pp(GemmParams p) {
   if (wm == 1) __builtin_amdgcn_s_barrier();
   const int last_quarter = 4 * nk - 1;
 
-  bf16x8 a[2][4], w[2][4];            // a[i & 1][s2]: A fragments of the current i-pair; w[j][s2]
+  bf16x8 a[HA][KS], w[2][HW][KS];     // A blocks of the current 64-row half; W blocks of both 32-column halves
   // one K-tile; STEADY: every phase still has kLead - 2 younger quarters in flight (no branches in the body)
   auto k_tile = [&](int t, auto steady) {
     constexpr bool STEADY = decltype(steady)::value;
@@ -468,31 +630,32 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_pp(GemmParams p) {
 #pragma unroll
     for (int ph = 0; ph < 4; ++ph) {
       // ---- READ section: this phase's fragments, one staging quarter kLead phases ahead, the counted wait
-      if (ph == 0) {
+      if (ph == 0 || ph == 1) {
 #pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {
-          w[0][s2] = frag(cur, P::kWOff, w_row_off, 0, s2);
-          a[0][s2] = frag(cur, 0, a_row_off, 0, s2);
-          a[1][s2] = frag(cur, 0, a_row_off, 1, s2);
-        }
-      } else if (ph == 1) {
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) w[1][s2] = frag(cur, P::kWOff, w_row_off, 1, s2);
-      } else if (ph == 2) {
+          for (int b = 0; b < HW; ++b) w[ph][b][ks] = frag(cur, P::kWOff, w_row_off, ph * HW + b, ks);
+      }
+      if (ph == 0 || ph == 2) {
 #pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {
-          a[0][s2] = frag(cur, 0, a_row_off, 2, s2);
-          a[1][s2] = frag(cur, 0, a_row_off, 3, s2);
-        }
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int b = 0; b < HA; ++b) a[b][ks] = frag(cur, 0, a_row_off, (ph / 2) * HA + b, ks);
       }
       // quarter g = k + kLead of the sequence (k = 4 t + ph)
       const int tt = t + (ph + kLead) / 4;
       const int sq = (ph + kLead) & 3;
+#ifdef LIST_PP_NO_LOAD        // ablation: only the prologue's quarters are ever staged (real data, no load stream)
+      if (false) {
+#else
       if (STEADY) {
+#endif
         stage_quarter(smem + (tt & 1) * P::kStageBytes, tt * P::kRowBytes, sq);
         wait_vmcnt<2 * (kLead - 2)>();     // my loads of every quarter up to k + 2 have landed
       } else {
+#ifndef LIST_PP_NO_LOAD
         if (tt < nk) stage_quarter(smem + (tt & 1) * P::kStageBytes, tt * P::kRowBytes, sq);
+#endif
         const int beyond = last_quarter - (4 * t + ph + 2);        // quarters issued beyond k + 2
         if (beyond >= 4) wait_vmcnt<2 * (kLead - 2 < 4 ? kLead - 2 : 4)>();
         else if (beyond == 3) wait_vmcnt<2 * (kLead - 2 < 3 ? kLead - 2 : 3)>();
@@ -500,38 +663,39 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_pp(GemmParams p) {
         else if (beyond == 1) wait_vmcnt<2>();
         else wait_vmcnt<0>();
       }
+      pp_fence();
       __builtin_amdgcn_s_barrier();
-      // ---- MFMA section: one 64 x 32 quadrant over the whole K-tile
+      // ---- MFMA section: one 64 x 32 quadrant over the whole K-tile, pinned between its two barriers
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const int i0 = ph < 2 ? 0 : 2, j = (ph == 0 || ph == 3) ? 0 : 1;
+      pp_fence();
+      pp_prio<1>();
+      const int ih = ph < 2 ? 0 : 1, jh = (ph == 0 || ph == 3) ? 0 : 1;
 #pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) {
-        acc[i0][j] = mfma<FP16>(a[0][s2], w[j][s2], acc[i0][j]);
-        acc[i0 + 1][j] = mfma<FP16>(a[1][s2], w[j][s2], acc[i0 + 1][j]);
-      }
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int bi = 0; bi < HA; ++bi)
+#pragma unroll
+          for (int bj = 0; bj < HW; ++bj) {
+#ifdef LIST_PP_NO_MFMA       // ablation: operands stay live, no MFMA issued
+            asm volatile("" ::"v"(a[bi][ks]), "v"(w[jh][bj][ks]));
+#else
+            auto& c = acc[ih * HA + bi][jh * HW + bj];
+            if constexpr (S16) c = mfma16<FP16>(a[bi][ks], w[jh][bj][ks], c);
+            else c = mfma<FP16>(a[bi][ks], w[jh][bj][ks], c);
+#endif
+          }
+      pp_prio<0>();
+      pp_fence();
       __builtin_amdgcn_s_barrier();
+      pp_fence();
     }
   };
   int t = 0;
   for (; t + 3 <= nk; ++t) k_tile(t, std::true_type());       // tiles 0 .. nk-3
   for (; t < nk; ++t) k_tile(t, std::false_type());           // the last two: fewer quarters left to fly
   if (wm == 0) __builtin_amdgcn_s_barrier();     // the first group waits for the second to catch up
-  gemm_epilogue<EPI, FP16>(p, acc, smem, m0, n0, wm, wn, wave, lane);
-}
-
-// ---- the same kernel on the 16x16x32 MFMA shape -----------------------------------------------------
-// Identical tiling, staging and pipeline; the wave's 128x64 outputs are 8x4 tiles of 16x16 (4
-// accumulator registers each).  Operand lane map: lane l holds A[row l&15][k = 8*(l>>4) .. +7] of a
-// 16x32 block; C/D: col = lane&15, row = 4*(lane>>4) + reg.  (MI355X holds a higher clock on this
-// shape under sustained MFMA load; launch_one dispatches whichever shape measured faster per epilogue.)
-typedef __attribute__((ext_vector_type(4))) float f32x4v;
-
-template <int FP16>
-__device__ __forceinline__ f32x4v mfma16(const bf16x8& a, const bf16x8& b, const f32x4v& c) {
-  if (FP16)
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b),
-                                                  c, 0, 0, 0);
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  if constexpr (S16) gemm_epilogue16<EPI, FP16>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+  else gemm_epilogue<EPI, FP16>(p, acc, smem, m0, n0, wm, wn, wave, lane);
 }
 
 template <int TERMS, int EPI, int FP16>
@@ -603,94 +767,27 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt16(GemmParams p) {
     }
   }
 
-  const int col_in = lane & 15, row_in = 4 * (lane >> 4);
-  if (EPI == EPI_RELU_SPLIT || EPI == EPI_F32) {
-    const int ld = EPI == EPI_F32 ? p.N : p.ldo;
-    const int64_t lane_off = (int64_t)(m0 + wm * 128 + row_in) * ld + n0 + wn * 64 + col_in;
-    float* of = EPI == EPI_F32 ? p.out_f32 + lane_off : nullptr;
-    unsigned short* oh = EPI == EPI_F32 ? nullptr : p.out_hi + lane_off;
-    unsigned short* ol = (EPI == EPI_F32 || !p.out_lo) ? nullptr : p.out_lo + lane_off;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float bias = p.bias ? p.bias[n0 + wn * 64 + j * 16 + col_in] : 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int off = (i * 16 + e) * ld + j * 16;
-          float v = acc[i][j][e] + bias;
-          if (EPI == EPI_F32) {
-            if (p.relu) v = relu_nan(v);
-            of[off] = v;
-          } else {
-            v = relu_nan(v);
-            const unsigned short h = to_half_plane<FP16>(v);
-            oh[off] = h;
-            if (!FP16 && ol) ol[off] = bf_lo(v, h);
-          }
-        }
-    }
-  } else {
-    float part[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) part[i][e] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = wn * 64 + j * 16 + col_in;      // n0 == 0 (N == BN)
-      const float bias = p.bias[col], w3 = p.w3[col];
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) part[i][e] += relu_nan(acc[i][j][e] + bias) * w3;
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float v = part[i][e];
-        v += __shfl_xor(v, 8);
-        v += __shfl_xor(v, 4);
-        v += __shfl_xor(v, 2);
-        v += __shfl_xor(v, 1);
-        part[i][e] = v;
-      }
-    __syncthreads();
-    float* red = (float*)smem;                         // [4 (wn)][256 rows]
-    if (col_in == 0) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) red[wn * 256 + wm * 128 + i * 16 + row_in + e] = part[i][e];
-    }
-    __syncthreads();
-    if (threadIdx.x < 256) {
-      const int row = m0 + threadIdx.x;
-      if (row < p.n_valid) {
-        const int rl = threadIdx.x;
-        p.sdf[p.order ? p.order[row] : row] =
-            ((red[rl] + red[256 + rl]) + (red[512 + rl] + red[768 + rl])) + p.b3[0];
-      }
-    }
-  }
+  gemm_epilogue16<EPI, FP16>(p, acc, smem, m0, n0, wm, wn, wave, lane);
 }
 
 template <int TERMS, int EPI, int FP16>
 static hipError_t launch_one(const GemmParams& p, hipStream_t s) {
   const int ntiles = (p.M / BM) * (p.N / BN);
-  // measured (fp16, P = 160k): the two shapes tie on fc_0 (0.58 ms, the kernel is bound by the LDS-DMA
-  // path, not by the MFMA clock); 32x32 has the cheaper 64-B store runs (fc_1 0.074 vs 0.086 ms), 16x16
-  // the cheaper row reduction of the fused fc_2 + fc_out epilogue (0.045 vs 0.058 ms)
+  // MFMA shape per epilogue (measured, fp16, P = 160k): 32x32x16 has the cheaper 64-B store runs on the short-K
+  // layers (fc_1 0.074 vs 0.086 ms), 16x16x32 the cheaper row reduction of the fused fc_2 + fc_out epilogue (0.045
+  // vs 0.058 ms) and, on the long-K ping-pong schedule, the higher clock (fc_0 0.55 -> 0.49 ms)
   if constexpr (EPI == EPI_RELU_DOT)
     hipLaunchKernelGGL((k_gemm_nt16<TERMS, EPI, FP16>), dim3(ntiles), dim3(512), 0, s, p);
   else {
 #ifndef LIST_GEMM_NO_PINGPONG
-    // the ping-pong schedule pays from ~16 K-tiles on (fc_0: 57; measured -6 %); shorter K (fc_1, dH, dX: 4-8
-    // K-tiles) is dominated by its prologue and stagger and stays on the plain 2-stage loop (+4 % there)
-    if constexpr (TERMS == 1) {
-      if (p.K >= 1024 && !p.plain_loop) {
-        hipLaunchKernelGGL((k_gemm_nt_pp<EPI, FP16>), dim3(ntiles), dim3(512), 0, s, p);
+    // the ping-pong schedule pays from ~16 K-tiles on (fc_0: 57); shorter K (fc_1, dH, dX: 4-8 K-tiles) is dominated
+    // by its prologue and stagger and stays on the plain 2-stage loop (+4 % there).  plain_loop (diagnostic) takes
+    // the plain loop of the SAME MFMA shape: bit-identical results, which makes it the schedule's race detector.
+    if constexpr (TERMS == 1 && (EPI == EPI_RELU_SPLIT || EPI == EPI_F32)) {
+      if (p.K >= 1024) {
+        if (!p.plain_loop) hipLaunchKernelGGL((k_gemm_nt_pp<EPI, FP16, kPpShape16>), dim3(ntiles), dim3(512), 0, s, p);
+        else if (kPpShape16) hipLaunchKernelGGL((k_gemm_nt16<TERMS, EPI, FP16>), dim3(ntiles), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((k_gemm_nt<TERMS, EPI, FP16>), dim3(ntiles), dim3(512), 0, s, p);
         return hipGetLastError();
       }
     }

@@ -85,7 +85,8 @@ def test_gemm_kernel_matches_fp64(hip, M, N, K):
 def test_pingpong_schedule_is_bit_identical_to_the_plain_loop(hip):
     """Long-K single-plane products run the ping-pong schedule (two wave groups one barrier apart, LDS-DMA
     quarters in flight behind counted vmcnt waits).  It accumulates in the same order as the plain 2-stage
-    loop, so any difference is a race: many shapes x repetitions must agree bit for bit."""
+    loop of the same MFMA shape (plain_loop=True), so any difference is a race: many shapes x repetitions
+    must agree bit for bit."""
     for rep in range(6):
         for (M, N, K) in [(256, 256, 1024), (512, 512, 3648), (2048, 256, 2048), (1024, 512, 1088)]:
             a = synth.normalish(100 + rep, (M, K))
