@@ -450,6 +450,35 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4v (&ac
     });
     // NaN probe for the exact redo of the row tile's gathers (see gemm_epilogue)
     if (p.nan_tiles && __builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) p.nan_tiles[m0 / BM] = 1;
+  } else if (EPI == EPI_MASK_SPLIT) {
+    const int64_t row_base = m0 + wm * 128;
+    const int col_base = n0 + wn * 64;
+    staged_epilogue16(acc, smem, wave, lane, [&](int r, int c8, const float (&v)[8]) {
+      const int64_t row = row_base + r;
+      const uint4 mk = *(const uint4*)(p.mask + row * p.ldmask + col_base + c8);
+      const unsigned mw[4] = {mk.x, mk.y, mk.z, mk.w};
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[2 * e] = (mw[e] & 0x7fffu) ? v[2 * e] : 0.f;
+        o[2 * e + 1] = (mw[e] & 0x7fff0000u) ? v[2 * e + 1] : 0.f;
+      }
+      store8_planes<FP16>(p.out_hi, p.out_lo, row * p.ldo + col_base + c8, o);
+    });
+  } else if (EPI == EPI_DX) {
+    const int64_t row_base = m0 + wm * 128;
+    const int col_base = n0 + wn * 64;
+    staged_epilogue16(acc, smem, wave, lane, [&](int r, int c8, const float (&v)[8]) {
+      if (col_base + c8 >= p.n_store) return;                  // n_store is a multiple of 8
+      const int64_t off = (row_base + r) * p.ldo + col_base + c8;
+      if (p.dx_f16) {
+        const uint2 a = half4(make_float4(v[0], v[1], v[2], v[3])), b = half4(make_float4(v[4], v[5], v[6], v[7]));
+        *(uint4*)((unsigned short*)p.dx + off) = make_uint4(a.x, a.y, b.x, b.y);
+      } else {
+        *(float4*)((float*)p.dx + off) = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)((float*)p.dx + off + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+    });
   } else if (EPI == EPI_F32) {
     const int64_t lane_off = (int64_t)(m0 + wm * 128 + row_in) * p.N + n0 + wn * 64 + col_in;
     float* of = p.out_f32 + lane_off;
@@ -790,6 +819,20 @@ static hipError_t launch_one(const GemmParams& p, hipStream_t s) {
         else hipLaunchKernelGGL((k_gemm_nt<TERMS, EPI, FP16>), dim3(ntiles), dim3(512), 0, s, p);
         return hipGetLastError();
       }
+    }
+#endif
+#ifndef LIST_X3_SHAPE32      // the hi/lo-split long-K product (fc_0 in bf16x3) on the 16x16x32 shape: 1.52 -> 1.43 ms
+    if constexpr (TERMS == 3 && EPI == EPI_RELU_SPLIT) {
+      if (p.K >= 1024) {
+        hipLaunchKernelGGL((k_gemm_nt16<TERMS, EPI, FP16>), dim3(ntiles), dim3(512), 0, s, p);
+        return hipGetLastError();
+      }
+    }
+#endif
+#ifndef LIST_BWD_SHAPE32     // the backward's data-gradient products (dX, dH) on the 16x16x32 shape: dX 0.87 -> 0.85 ms
+    if constexpr (EPI == EPI_DX || EPI == EPI_MASK_SPLIT) {
+      hipLaunchKernelGGL((k_gemm_nt16<TERMS, EPI, FP16>), dim3(ntiles), dim3(512), 0, s, p);
+      return hipGetLastError();
     }
 #endif
     hipLaunchKernelGGL((k_gemm_nt<TERMS, EPI, FP16>), dim3(ntiles), dim3(512), 0, s, p);

@@ -2,7 +2,8 @@
 set -o pipefail
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-LIST_HIPCC_FLAGS="-DLIST_PREP_PER_LEVEL" python learning-implicitly-from-spatial-transformers-network_amd/build.py --force > /dev/null 2>&1
+# build HERE first: bash tools/variants.sh perlevel="-DLIST_PREP_PER_LEVEL"
+export LIST_HIP_LIB=$PWD/variants/${VARIANT:-perlevel}.so
 export TMPDIR=/tmp
 rm -rf gpurun_out/prof_prep
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_prep -- python3 tools/prof_prep.py > gpurun_out/prof_prep.log 2>&1
@@ -16,7 +17,7 @@ by = collections.defaultdict(list)
 for r in rows:
     n = r["Kernel_Name"]
     if "k_prep_img_rows" in n or "transpose" in n:
-        by[(n[:60], r["Grid_Size"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        by[(n[:60], r.get("Grid_Size_X", r.get("Grid_Size")))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 for k, v in by.items():
     v = sorted(v)
     print(f"{k[0]:62s} grid {k[1]:>10s}  n {len(v):3d}  median {v[len(v)//2]:8.1f} us  min {v[0]:8.1f}")
