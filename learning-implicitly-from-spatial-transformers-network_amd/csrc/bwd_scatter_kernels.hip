@@ -76,6 +76,65 @@ __global__ __launch_bounds__(256) void k_scatter_vox(ScatterParams sp, ListVoxLe
   }
 }
 
+// fp16 operands, levels whose tap run is two or more 64-B atomic requests in fp32 (C >= 32): the direct form's
+// time follows the atomic BYTES there (same 9 M tap runs per launch: C = 16 / 64 B 0.51 ms, C = 32 / 128 B 0.89 ms),
+// so the runs are added as packed halfs (global_atomic_pk_add_f16, lanes over channel PAIRS) into a zeroed fp16 image
+// of the level kept at the gradient scale s (the dX operand is s * dX already, fp16), and one streaming pass
+// writes (1/s) * image as the fp32 gradient (which then needs no memset).  A voxel of these sparse levels sums a few
+// contributions, each rounded to 11 bits -- far inside the fp16 mode's gradient noise; the fp32-grade
+// mode never takes this form.
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+template <int C>
+__global__ __launch_bounds__(256) void k_scatter_vox_h2(ScatterParams sp, ListVoxLevel gv, int col_off, int nblocks,
+                                                        _Float16* __restrict__ img16) {
+  __shared__ Pt pts[kScatterRows];
+  constexpr int CP = C / 2, per_pass = 256 / CP;
+  const int tid = threadIdx.x, cp = tid % CP;
+  for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    __syncthreads();
+    if (threadIdx.x < kScatterRows) pts[threadIdx.x] = load_point(sp.g, blk * kScatterRows + threadIdx.x);
+    __syncthreads();
+    const int64_t row0 = (int64_t)blk * kScatterRows;
+    for (int it = tid / CP; it < kScatterRows * LIST_N_STENCIL; it += per_pass) {
+      const int r = it / LIST_N_STENCIL, j = it - r * LIST_N_STENCIL;
+      const Pt p = pts[r];
+      if (!p.valid) continue;
+      float x, y, z;
+      stencil_rt(p, j, x, y, z);
+      const Taps t = make_taps(x, y, z, C, gv.D, gv.H, gv.W);
+      const unsigned g2 = *(const unsigned*)((const unsigned short*)sp.dx + (row0 + r) * sp.g.Kp + col_off + j * C + 2 * cp);
+      const float g0 = h2f((unsigned short)(g2 & 0xffffu)), g1 = h2f((unsigned short)(g2 >> 16));
+      _Float16* base = img16 + (int64_t)p.b * gv.image_stride + 2 * cp;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        half2v v;
+        v.x = (_Float16)(t.w[k] * g0); v.y = (_Float16)(t.w[k] * g1);
+        __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2v*)(base + t.o[k]), v);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_h16_to_grad(const _Float16* __restrict__ img16, float* __restrict__ out,
+                                                     int64_t n8, const float* __restrict__ scale) {
+  const float inv_s = scale[1];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+    const u4 r = __builtin_nontemporal_load((const u4*)img16 + i);
+    const unsigned w[4] = {r.x, r.y, r.z, r.w};
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[2 * e] = h2f((unsigned short)(w[e] & 0xffffu)) * inv_s;
+      o[2 * e + 1] = h2f((unsigned short)(w[e] >> 16)) * inv_s;
+    }
+    typedef __attribute__((ext_vector_type(4))) float f4;
+    __builtin_nontemporal_store((f4){o[0], o[1], o[2], o[3]}, (f4*)out + 2 * i);
+    __builtin_nontemporal_store((f4){o[4], o[5], o[6], o[7]}, (f4*)out + 2 * i + 1);
+  }
+}
+
 // Coarse levels (stencil shorter than a voxel: 16^3 and 8^3, 58 % of all tap contributions): a run of
 // Morton-consecutive points touches a small box of voxels, so its contributions are summed in an LDS
 // window first and the window is flushed once (8-50x fewer global atomics).  LDS float atomics are slow on
@@ -528,6 +587,32 @@ hipError_t launch_scatter_vox(const ScatterParams& sp, const FeatLayout& L, cons
       continue;
     }
     hipStream_t s = (window_level && vb.mode != 2) ? st.window : st.direct;
+#ifndef LIST_BWD_NO_PK_ATOMICS
+    // packed-half atomics (see k_scatter_vox_h2): fp16 operands, automatic form choice, C = 32 or a non-window C = 64
+    // level, and the level's fp16 image fits the scratch the caller set aside
+    {
+      const size_t n_elem = (size_t)B * gv.image_stride;
+      if (sp.dx_f16 && vb.mode == 0 && !window_level && (gv.C == 32 || gv.C == 64) && vb.h16 &&
+          n_elem * 2 <= vb.h16_bytes && n_elem % 8 == 0 && gv.image_stride == (int64_t)gv.D * gv.H * gv.W * gv.C) {
+        e = hipMemsetAsync(vb.h16, 0, n_elem * 2, s);
+        if (e != hipSuccess) return e;
+        const int nblocks = sp.g.rows / kScatterRows;
+        const int cap = sp.forked ? kDirectGridForked : kDirectGrid;
+        const dim3 pgrid((unsigned)(nblocks < cap ? nblocks : cap));
+        if (gv.C == 32)
+          hipLaunchKernelGGL(k_scatter_vox_h2<32>, pgrid, dim3(256), 0, s, sp, gv, L.vox_off[l], nblocks, (_Float16*)vb.h16);
+        else
+          hipLaunchKernelGGL(k_scatter_vox_h2<64>, pgrid, dim3(256), 0, s, sp, gv, L.vox_off[l], nblocks, (_Float16*)vb.h16);
+        const int64_t n8 = (int64_t)(n_elem / 8);
+        const int64_t cb = (n8 + 255) / 256;
+        hipLaunchKernelGGL(k_h16_to_grad, dim3((unsigned)(cb < 8192 ? cb : 8192)), dim3(256), 0, s,
+                           (const _Float16*)vb.h16, (float*)gv.data, n8, sp.scale);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        continue;
+      }
+    }
+#endif
     e = hipMemsetAsync((void*)gv.data, 0, (size_t)B * gv.image_stride * sizeof(float), s);
     if (e != hipSuccess) return e;
     if (gv.C == 1) {

@@ -590,6 +590,10 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   VoxGatherBuffers vb;
   vb.keys = (int*)(bwp + bw.vs_keys); vb.bins = (int*)(bwp + bw.vs_bins); vb.sums = (int*)(bwp + bw.vs_sums);
   vb.recs = bwp + bw.vs_recs; vb.mode = ga->vox_adjoint;
+  // fp16 operands leave the lo planes of the backward workspace unused: the dZ1 lo plane (rows x H1 halfs) is the
+  // scratch of the packed-half atomics (a level whose fp16 image does not fit it keeps the fp32 atomics)
+  vb.h16 = fp16 ? (void*)(bwp + bw.dz1_lo) : nullptr;
+  vb.h16_bytes = fp16 ? (size_t)rows * a->H1 * 2 : 0;
   const ScatterStreams sst = {s, s_direct, s_window};
 
   mark(LIST_BWD_BEGIN);

@@ -204,6 +204,25 @@ def test_voxel_adjoint_forms_agree_with_the_reference(hip, golden_dir, name):
             assert rel_max(a, g[k]) < TOL_X3_RELMAX, (mode, k, rel_max(a, g[k]))
 
 
+def test_packed_half_atomics_agree_with_the_fp32_atomics(hip):
+    """fp16 operands: a sparse C = 32 level whose fp16 image fits the scratch takes packed-half atomics
+    (global_atomic_pk_add_f16 into an image kept at the gradient scale, then one pass to fp32); forcing the direct
+    form (vox_adjoint='scatter') keeps fp32 atomics on the same dX.  A voxel sums a handful of contributions, each
+    rounded to 11 bits: the two agree to ~1e-3 of the level's largest entry and are not the same bits."""
+    c = cases._case(seed=515, batch=2, n=500, img_res=64, vox_res=32)      # level 2: 16^3 x 32, 0.85 samples per cell
+    gs = synth.normalish(9, (2, 500))
+    _, a = hip_gradients(hip, c, gs, "fp16", want=dict(want_mlp=False, want_img=False, want_trans=False))
+    _, b = hip_gradients(hip, c, gs, "fp16", want=dict(want_mlp=False, want_img=False, want_trans=False,
+                                                       vox_adjoint="scatter"))
+    assert np.isfinite(a["d_vox2"]).all()
+    assert rel_max(a["d_vox2"], b["d_vox2"]) < 2e-3
+    assert not np.array_equal(a["d_vox2"], b["d_vox2"])                    # the packed form did run
+    _, ref = hip_gradients(hip, c, gs, "bf16x3", want=dict(want_mlp=False, want_img=False, want_trans=False))
+    assert rel_l2(a["d_vox2"], ref["d_vox2"]) < TOL_L2["fp16"]
+    for k in ("d_vox0", "d_vox1", "d_vox3", "d_vox4", "d_vox5"):           # the other levels: same forms either way
+        assert rel_max(a[k], b[k]) < 1e-4, k
+
+
 def test_backward_large_batch_statistics(hip):
     """B = 8 x 6000 points (several Morton runs per voxel, many workgroups per image, rows padded): the
     HIP gradients in fp16 against the HIP gradients in bf16x3 (same kernels, 2-4 % mask-flip noise), and
