@@ -809,11 +809,15 @@ static hipError_t launch_one(const GemmParams& p, hipStream_t s) {
     hipLaunchKernelGGL((k_gemm_nt16<TERMS, EPI, FP16>), dim3(ntiles), dim3(512), 0, s, p);
   else {
 #ifndef LIST_GEMM_NO_PINGPONG
-    // the ping-pong schedule pays from ~16 K-tiles on (fc_0: 57); shorter K (fc_1, dH, dX: 4-8 K-tiles) is dominated
-    // by its prologue and stagger and stays on the plain 2-stage loop (+4 % there).  plain_loop (diagnostic) takes
-    // the plain loop of the SAME MFMA shape: bit-identical results, which makes it the schedule's race detector.
-    if constexpr (TERMS == 1 && (EPI == EPI_RELU_SPLIT || EPI == EPI_F32)) {
-      if (p.K >= 1024) {
+    // the ping-pong schedule pays from 8 K-tiles on (fc_0: 57 K-tiles; fc_1 0.088 -> 0.081 ms and dX 0.82 -> 0.78 ms at
+    // 8); at 4 K-tiles (dH) its prologue and stagger cancel the gain and the plain 2-stage loop stays.  plain_loop
+    // (diagnostic) takes the plain loop of the SAME MFMA shape: bit-identical results, which makes it the schedule's
+    // race detector.
+#ifndef LIST_PP_MIN_K
+#define LIST_PP_MIN_K 512
+#endif
+    if constexpr (TERMS == 1 && (EPI == EPI_RELU_SPLIT || EPI == EPI_F32 || (kPpShape16 && (EPI == EPI_DX || EPI == EPI_MASK_SPLIT)))) {
+      if (p.K >= LIST_PP_MIN_K) {
         if (!p.plain_loop) hipLaunchKernelGGL((k_gemm_nt_pp<EPI, FP16, kPpShape16>), dim3(ntiles), dim3(512), 0, s, p);
         else if (kPpShape16) hipLaunchKernelGGL((k_gemm_nt16<TERMS, EPI, FP16>), dim3(ntiles), dim3(512), 0, s, p);
         else hipLaunchKernelGGL((k_gemm_nt<TERMS, EPI, FP16>), dim3(ntiles), dim3(512), 0, s, p);

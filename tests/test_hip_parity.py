@@ -88,7 +88,7 @@ def test_pingpong_schedule_is_bit_identical_to_the_plain_loop(hip):
     loop of the same MFMA shape (plain_loop=True), so any difference is a race: many shapes x repetitions
     must agree bit for bit."""
     for rep in range(6):
-        for (M, N, K) in [(256, 256, 1024), (512, 512, 3648), (2048, 256, 2048), (1024, 512, 1088)]:
+        for (M, N, K) in [(256, 256, 1024), (512, 512, 3648), (2048, 256, 2048), (1024, 512, 1088), (768, 256, 512)]:
             a = synth.normalish(100 + rep, (M, K))
             w = synth.uniform(200 + rep, (N, K), -0.05, 0.05)
             for prec in ("fp16", "bf16"):
