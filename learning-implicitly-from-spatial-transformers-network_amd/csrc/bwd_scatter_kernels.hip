@@ -117,8 +117,8 @@ __global__ __launch_bounds__(256) void k_scatter_vox_h2(ScatterParams sp, ListVo
 }
 
 __global__ __launch_bounds__(256) void k_h16_to_grad(const _Float16* __restrict__ img16, float* __restrict__ out,
-                                                     int64_t n8, const float* __restrict__ scale) {
-  const float inv_s = scale[1];
+                                                     int64_t n8, const float* __restrict__ scale, float unscale) {
+  const float inv_s = scale[1] * unscale;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
     typedef __attribute__((ext_vector_type(4))) unsigned u4;
     const u4 r = __builtin_nontemporal_load((const u4*)img16 + i);
@@ -204,9 +204,43 @@ __device__ __forceinline__ void build_near(const Pt& p, int W, int H, int D, con
 
 // kWinFloats: 18432 (72 KB, two workgroups per CU) for the 16^3 level, whose runs need ~100-voxel boxes;
 // 9216 (36 KB, four per CU) for the 8^3 level
+// fp16 image of a window level: kept at the gradient scale times kWinPkScale (headroom: a coarse voxel sums
+// thousands of taps)
+constexpr float kWinPkScale = 0.0625f;
+// a run whose box does not fit the window, packed-half form: lanes over channel pairs, taps at the window scale
+template <int C, int T>
+__device__ __forceinline__ void scatter_direct_h2(const ScatterParams& sp, const ListVoxLevel& gv, int col_off,
+                                                  const Pt* __restrict__ pts, int r_begin, int r_end, int64_t row0,
+                                                  _Float16* __restrict__ img16) {
+  constexpr int CP = C / 2, per_pass = (T / CP) > 0 ? (T / CP) : 1;
+  const int tid = threadIdx.x;
+  if (tid >= per_pass * CP) return;
+  const int cp = tid % CP;
+  for (int it = r_begin * LIST_N_STENCIL + tid / CP; it < r_end * LIST_N_STENCIL; it += per_pass) {
+    const int r = it / LIST_N_STENCIL, j = it - r * LIST_N_STENCIL;
+    const Pt p = pts[r];
+    if (!p.valid) continue;
+    float x, y, z;
+    stencil_rt(p, j, x, y, z);
+    const Taps t = make_taps(x, y, z, C, gv.D, gv.H, gv.W);
+    const unsigned g2 = *(const unsigned*)((const unsigned short*)sp.dx + (row0 + r) * sp.g.Kp + col_off + j * C + 2 * cp);
+    const float g0 = h2f((unsigned short)(g2 & 0xffffu)) * kWinPkScale, g1 = h2f((unsigned short)(g2 >> 16)) * kWinPkScale;
+    _Float16* base = img16 + (int64_t)p.b * gv.image_stride + 2 * cp;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      half2v v;
+      v.x = (_Float16)(t.w[k] * g0); v.y = (_Float16)(t.w[k] * g1);
+      __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2v*)(base + t.o[k]), v);
+    }
+  }
+}
+
+// img16 != nullptr (fp16 operands): the window is flushed as packed halfs into a zeroed fp16 image of the level
+// (scale above) and k_h16_to_grad writes the fp32 gradient afterwards -- half the atomic bytes of the flush that
+// bounds these levels.
 template <int C, int DXH, int kWinFloats>
 __global__ __launch_bounds__((C >= 128 ? C : 128)) void k_scatter_vox_win(ScatterParams sp, ListVoxLevel gv,
-                                                                             int col_off) {
+                                                                             int col_off, _Float16* __restrict__ img16) {
   constexpr int T = C >= 128 ? C : 128;
   constexpr int COPIES = T / C;
   constexpr int MYP = kSubPts / COPIES;              // points per copy per chunk
@@ -271,7 +305,8 @@ __global__ __launch_bounds__((C >= 128 ? C : 128)) void k_scatter_vox_win(Scatte
   for (int ri = 0; ri < nr; ++ri) {
     const Run r = runs[ri];
     if (r.direct) {
-      scatter_direct<C, DXH, T>(sp, gv, col_off, pts, r.first, r.first + r.count, row0, inv_s);
+      if (DXH && img16) scatter_direct_h2<C, T>(sp, gv, col_off, pts, r.first, r.first + r.count, row0, img16);
+      else scatter_direct<C, DXH, T>(sp, gv, col_off, pts, r.first, r.first + r.count, row0, inv_s);
       continue;
     }
     const int nx = r.nx, ny = r.ny, vol = r.nx * r.ny * r.nz;
@@ -326,15 +361,34 @@ __global__ __launch_bounds__((C >= 128 ? C : 128)) void k_scatter_vox_win(Scatte
       }
     }
     __syncthreads();
-    float* base = gout + (int64_t)r.b * gv.image_stride;
-    for (int i = tid; i < vol * C; i += T) {
-      const int vox = i / C, cc = i - vox * C;
-      float sum = 0.f;
+    if (DXH && img16) {
+      _Float16* base16 = img16 + (int64_t)r.b * gv.image_stride;
+      for (int i = tid; i < vol * (C / 2); i += T) {
+        const int vox = i / (C / 2), cc = 2 * (i - vox * (C / 2));
+        float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-      for (int kk = 0; kk < COPIES; ++kk) sum += win[(kk * (vol + 1) + vox) * C + cc];
-      if (sum == 0.f) continue;
-      const int vx = vox % nx, vy = (vox / nx) % ny, vz = vox / (nx * ny);
-      atomicAdd(base + ((int64_t)((r.oz + vz) * H + (r.oy + vy)) * W + (r.ox + vx)) * C + cc, sum * inv_s);
+        for (int kk = 0; kk < COPIES; ++kk) {
+          const float2 w2 = *(const float2*)(win + (kk * (vol + 1) + vox) * C + cc);
+          s0 += w2.x; s1 += w2.y;
+        }
+        if (s0 == 0.f && s1 == 0.f) continue;
+        const int vx = vox % nx, vy = (vox / nx) % ny, vz = vox / (nx * ny);
+        half2v v;
+        v.x = (_Float16)(s0 * kWinPkScale); v.y = (_Float16)(s1 * kWinPkScale);
+        __builtin_amdgcn_global_atomic_fadd_v2f16(
+            (__attribute__((address_space(1))) half2v*)(base16 + ((int64_t)((r.oz + vz) * H + (r.oy + vy)) * W + (r.ox + vx)) * C + cc), v);
+      }
+    } else {
+      float* base = gout + (int64_t)r.b * gv.image_stride;
+      for (int i = tid; i < vol * C; i += T) {
+        const int vox = i / C, cc = i - vox * C;
+        float sum = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < COPIES; ++kk) sum += win[(kk * (vol + 1) + vox) * C + cc];
+        if (sum == 0.f) continue;
+        const int vx = vox % nx, vy = (vox / nx) % ny, vz = vox / (nx * ny);
+        atomicAdd(base + ((int64_t)((r.oz + vz) * H + (r.oy + vy)) * W + (r.ox + vx)) * C + cc, sum * inv_s);
+      }
     }
     __syncthreads();                                 // the next run re-zeroes the window
   }
@@ -540,7 +594,8 @@ __global__ __launch_bounds__(256) void k_scatter_vox1(ScatterParams sp, ListVoxL
 }
 
 template <int C>
-static hipError_t scatter_level(const ScatterParams& sp, const ListVoxLevel& gv, int col_off, hipStream_t s) {
+static hipError_t scatter_level(const ScatterParams& sp, const ListVoxLevel& gv, int col_off, hipStream_t s,
+                                _Float16* img16 = nullptr) {
   const dim3 grid((unsigned)(sp.g.rows / kScatterRows));
   const int big = gv.W > gv.H ? (gv.W > gv.D ? gv.W : gv.D) : (gv.H > gv.D ? gv.H : gv.D);
   const float reach = kDisp * 0.5f * (float)(big - 1);          // stencil displacement in voxels
@@ -548,11 +603,11 @@ static hipError_t scatter_level(const ScatterParams& sp, const ListVoxLevel& gv,
     if (reach < 0.99f) {
       constexpr int T = C >= 128 ? C : 128;
       if (reach < 0.34f) {          // 8^3: small boxes, four workgroups per CU
-        if (sp.dx_f16) hipLaunchKernelGGL((k_scatter_vox_win<C, 1, 9216>), grid, dim3(T), 0, s, sp, gv, col_off);
-        else hipLaunchKernelGGL((k_scatter_vox_win<C, 0, 9216>), grid, dim3(T), 0, s, sp, gv, col_off);
+        if (sp.dx_f16) hipLaunchKernelGGL((k_scatter_vox_win<C, 1, 9216>), grid, dim3(T), 0, s, sp, gv, col_off, img16);
+        else hipLaunchKernelGGL((k_scatter_vox_win<C, 0, 9216>), grid, dim3(T), 0, s, sp, gv, col_off, (_Float16*)nullptr);
       } else {
-        if (sp.dx_f16) hipLaunchKernelGGL((k_scatter_vox_win<C, 1, 18432>), grid, dim3(T), 0, s, sp, gv, col_off);
-        else hipLaunchKernelGGL((k_scatter_vox_win<C, 0, 18432>), grid, dim3(T), 0, s, sp, gv, col_off);
+        if (sp.dx_f16) hipLaunchKernelGGL((k_scatter_vox_win<C, 1, 18432>), grid, dim3(T), 0, s, sp, gv, col_off, img16);
+        else hipLaunchKernelGGL((k_scatter_vox_win<C, 0, 18432>), grid, dim3(T), 0, s, sp, gv, col_off, (_Float16*)nullptr);
       }
       return hipGetLastError();
     }
@@ -570,6 +625,7 @@ hipError_t launch_scatter_vox(const ScatterParams& sp, const FeatLayout& L, cons
                               const ScatterStreams& st) {
   (void)a;
   const int B = (int)((sp.g.p_begin + sp.g.n_valid + sp.g.N - 1) / sp.g.N);
+  int n_win_pk = 0;
   for (int l = 0; l < LIST_N_VOX_LEVELS; ++l) {
     const ListVoxLevel& gv = grad_vox[l];
     if (!gv.data) continue;
@@ -612,7 +668,35 @@ hipError_t launch_scatter_vox(const ScatterParams& sp, const FeatLayout& L, cons
         const int64_t n8 = (int64_t)(n_elem / 8);
         const int64_t cb = (n8 + 255) / 256;
         hipLaunchKernelGGL(k_h16_to_grad, dim3((unsigned)(cb < 8192 ? cb : 8192)), dim3(256), 0, s,
-                           (const _Float16*)vb.h16, (float*)gv.data, n8, sp.scale);
+                           (const _Float16*)vb.h16, (float*)gv.data, n8, sp.scale, 1.f);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        continue;
+      }
+    }
+#endif
+#ifndef LIST_BWD_NO_PK_ATOMICS
+    // window levels, fp16 operands: packed-half flush into the level's fp16 image (its own scratch slot: the window
+    // levels run beside the direct ones), then one pass to fp32
+    if (window_level && sp.dx_f16 && vb.mode == 0 && (gv.C == 64 || gv.C == 128 || gv.C == 256) && vb.h16w) {
+      const size_t n_elem = (size_t)B * gv.image_stride;
+      const size_t slot = vb.h16w_bytes / 2 / 256 * 256;         // two window levels at most share the scratch
+      char* img = (char*)vb.h16w + (size_t)(n_win_pk & 1) * slot;
+      if (n_elem * 2 <= slot && n_elem % 8 == 0 && n_win_pk < 2 &&
+          gv.image_stride == (int64_t)gv.D * gv.H * gv.W * gv.C) {
+        ++n_win_pk;
+        e = hipMemsetAsync(img, 0, n_elem * 2, s);
+        if (e != hipSuccess) return e;
+        switch (gv.C) {
+          case 64: e = scatter_level<64>(sp, gv, L.vox_off[l], s, (_Float16*)img); break;
+          case 128: e = scatter_level<128>(sp, gv, L.vox_off[l], s, (_Float16*)img); break;
+          default: e = scatter_level<256>(sp, gv, L.vox_off[l], s, (_Float16*)img); break;
+        }
+        if (e != hipSuccess) return e;
+        const int64_t n8 = (int64_t)(n_elem / 8);
+        const int64_t cb = (n8 + 255) / 256;
+        hipLaunchKernelGGL(k_h16_to_grad, dim3((unsigned)(cb < 8192 ? cb : 8192)), dim3(256), 0, s,
+                           (const _Float16*)img, (float*)gv.data, n8, sp.scale, 1.f / kWinPkScale);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         continue;

@@ -594,6 +594,8 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   // scratch of the packed-half atomics (a level whose fp16 image does not fit it keeps the fp32 atomics)
   vb.h16 = fp16 ? (void*)(bwp + bw.dz1_lo) : nullptr;
   vb.h16_bytes = fp16 ? (size_t)rows * a->H1 * 2 : 0;
+  vb.h16w = fp16 ? (void*)(bwp + bw.dz2_lo) : nullptr;               // window levels: the dZ2 lo plane
+  vb.h16w_bytes = fp16 ? (size_t)rows * a->H2 * 2 : 0;
   const ScatterStreams sst = {s, s_direct, s_window};
 
   mark(LIST_BWD_BEGIN);

@@ -413,8 +413,9 @@ struct ScatterParams {
 // buffers of the voxel-side gather (bwd_scatter_kernels.hip); bins == nullptr disables it
 constexpr int64_t kVoxGatherMaxBins = 4194304;      // cells (B * D * H * W) a level may have
 constexpr double kVoxGatherMinDensity = LIST_VOX_GATHER_MIN_DENSITY;   // samples per cell
-// mode: ListQueryGradArgs.vox_adjoint; h16: scratch for a level's fp16 image (packed-half atomics), or null
-struct VoxGatherBuffers { int* keys; int* bins; int* sums; void* recs; int mode; void* h16; size_t h16_bytes; };
+// mode: ListQueryGradArgs.vox_adjoint; h16 / h16w: scratch for the fp16 image of a direct level / of the two window
+// levels (packed-half atomics), or null
+struct VoxGatherBuffers { int* keys; int* bins; int* sums; void* recs; int mode; void* h16; size_t h16_bytes; void* h16w; size_t h16w_bytes; };
 // the three adjoint forms may run on different streams (gather / direct atomics / LDS windows)
 struct ScatterStreams { hipStream_t gather, direct, window; };
 hipError_t launch_scatter_vox(const ScatterParams& sp, const FeatLayout& L, const ListQueryArgs& a,

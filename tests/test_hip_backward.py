@@ -205,7 +205,7 @@ def test_voxel_adjoint_forms_agree_with_the_reference(hip, golden_dir, name):
 
 
 def test_packed_half_atomics_agree_with_the_fp32_atomics(hip):
-    """fp16 operands: a sparse C = 32 level whose fp16 image fits the scratch takes packed-half atomics
+    """fp16 operands: a sparse C = 32 level whose fp16 image fits the scratch, and the LDS-window levels, take packed-half atomics
     (global_atomic_pk_add_f16 into an image kept at the gradient scale, then one pass to fp32); forcing the direct
     form (vox_adjoint='scatter') keeps fp32 atomics on the same dX.  A voxel sums a handful of contributions, each
     rounded to 11 bits: the two agree to ~1e-3 of the level's largest entry and are not the same bits."""
@@ -219,8 +219,13 @@ def test_packed_half_atomics_agree_with_the_fp32_atomics(hip):
     assert not np.array_equal(a["d_vox2"], b["d_vox2"])                    # the packed form did run
     _, ref = hip_gradients(hip, c, gs, "bf16x3", want=dict(want_mlp=False, want_img=False, want_trans=False))
     assert rel_l2(a["d_vox2"], ref["d_vox2"]) < TOL_L2["fp16"]
-    for k in ("d_vox0", "d_vox1", "d_vox3", "d_vox4", "d_vox5"):           # the other levels: same forms either way
+    for k in ("d_vox0", "d_vox1"):                                          # fp32 atomics either way
         assert rel_max(a[k], b[k]) < 1e-4, k
+    # the LDS-window levels flush as packed halfs too (tens of flush-adds per voxel, each rounded to 11 bits)
+    for k in ("d_vox3", "d_vox4", "d_vox5"):
+        assert np.isfinite(a[k]).all(), k
+        assert rel_max(a[k], b[k]) < 5e-3, (k, rel_max(a[k], b[k]))
+        assert rel_l2(a[k], ref[k]) < TOL_L2["fp16"], k
 
 
 def test_backward_large_batch_statistics(hip):
