@@ -1132,8 +1132,22 @@ __device__ __forceinline__ void adj_footprint(int o, int S, int ms, int& i0, int
 
 constexpr int kAdjTileW = 128;             // source columns per pass of phases 2-3
 
-__global__ __launch_bounds__(256) void k_img_grad_level(const float* __restrict__ G, int ms, int Ct, int coff,
-                                                        ListMap2D m, int maxper) {
+// All levels in ONE launch: a level's workgroups are few (896 - 1792) and each is a chain of dependent steps (tap
+// lists, the row loop, two LDS phases), so five launches in a row cost ~0.11 ms each whatever their bytes; side by
+// side the small levels fill the gaps of the large ones.
+struct AdjLevels { ListMap2D m[LIST_N_IMG_LEVELS]; int coff[LIST_N_IMG_LEVELS], maxper[LIST_N_IMG_LEVELS],
+                   wg_begin[LIST_N_IMG_LEVELS], n; };
+
+__global__ __launch_bounds__(256) void k_img_grad_level(const float* __restrict__ G, int ms, int Ct, AdjLevels lv) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < LIST_N_IMG_LEVELS; ++i)
+    if (i < lv.n && (int)blockIdx.x >= lv.wg_begin[i]) l = i;
+  const ListMap2D m = lv.m[l];
+  const int coff = lv.coff[l], maxper = lv.maxper[l];
+  const int cgroups = (m.C + 63) / 64;
+  const int widx = (int)blockIdx.x - lv.wg_begin[l];
+  const int bx = widx / cgroups, by = widx - bx * cgroups;      // (image, source row) and 64-channel group
   extern __shared__ __attribute__((aligned(16))) float dyn[];
   // dynamic LDS: R[ms][64] | tile[64][kAdjTileW + 1] | wy[ms] | wx[W][maxper] | ox_first[W] | ox_cnt[W]
   float* R = dyn;
@@ -1143,9 +1157,9 @@ __global__ __launch_bounds__(256) void k_img_grad_level(const float* __restrict_
   int* ox_first = (int*)(s_wx + m.W * maxper);
   int* ox_cnt = ox_first + m.W;
   __shared__ int oy_range[2];
-  const int ys = blockIdx.x % m.H;
-  const int b = blockIdx.x / m.H;
-  const int c0 = blockIdx.y * 64;
+  const int ys = bx % m.H;
+  const int b = bx / m.H;
+  const int c0 = by * 64;
   if (threadIdx.x == 0) { oy_range[0] = INT_MAX; oy_range[1] = INT_MIN; }
   __syncthreads();
   // map rows that touch source row ys: footprints are monotone, so they form one contiguous range
@@ -1312,7 +1326,11 @@ hipError_t launch_grad_to_rows(const float* src, int64_t sb, int64_t sc, int64_t
 hipError_t launch_img_grad_to_levels(const float* grad_img_map, int B, int map_size, int Ct,
                                      const ListMap2D grads[LIST_N_IMG_LEVELS], hipStream_t s) {
   if (map_size > kAdjMaxMs) return hipErrorInvalidValue;
+  AdjLevels lv;
+  lv.n = 0;
   int coff = 0;
+  int64_t wgs = 0;
+  size_t lds = 0;
   for (int i = 0; i < LIST_N_IMG_LEVELS; ++i) {
     const ListMap2D& m = grads[i];
     if (m.data) {
@@ -1321,22 +1339,24 @@ hipError_t launch_img_grad_to_levels(const float* grad_img_map, int B, int map_s
       const float scx = map_size > 1 ? (float)(m.W - 1) / (float)(map_size - 1) : 0.f;
       int maxper = scx > 0.f ? (int)(2.f / scx) + 4 : map_size;
       if (maxper > map_size) maxper = map_size;
-      const size_t lds = sizeof(float) * ((size_t)map_size * 64 + 64 * (size_t)(kAdjTileW + 1) + (size_t)map_size +
-                                          (size_t)m.W * maxper) + sizeof(int) * 2 * (size_t)m.W;
-      if (lds > 150 * 1024) return hipErrorInvalidValue;
-      if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_img_grad_level, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds);
-        if (e != hipSuccess) return e;
-      }
-      const dim3 grid((unsigned)(B * m.H), (unsigned)((m.C + 63) / 64));
-      hipLaunchKernelGGL(k_img_grad_level, grid, dim3(256), lds, s, grad_img_map, map_size, Ct, coff, m, maxper);
-      hipError_t e = hipGetLastError();
-      if (e != hipSuccess) return e;
+      const size_t need = sizeof(float) * ((size_t)map_size * 64 + 64 * (size_t)(kAdjTileW + 1) + (size_t)map_size +
+                                           (size_t)m.W * maxper) + sizeof(int) * 2 * (size_t)m.W;
+      if (need > 150 * 1024) return hipErrorInvalidValue;
+      if (need > lds) lds = need;
+      const int k = lv.n++;
+      lv.m[k] = m; lv.coff[k] = coff; lv.maxper[k] = maxper; lv.wg_begin[k] = (int)wgs;
+      wgs += (int64_t)B * m.H * ((m.C + 63) / 64);
     }
     coff += m.C;
   }
-  return hipSuccess;
+  if (lv.n == 0) return hipSuccess;
+  if (wgs >= 2147483647LL) return hipErrorInvalidValue;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_img_grad_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(k_img_grad_level, dim3((unsigned)wgs), dim3(256), lds, s, grad_img_map, map_size, Ct, lv);
+  return hipGetLastError();
 }
 
 }  // namespace list
