@@ -89,8 +89,11 @@ def test_two_threads_on_their_own_streams_match_the_sequential_run(hip, precisio
                 tol = 1e-4 * float(r_mlp[k].abs().max()) + 1e-12
                 assert float((v - r_mlp[k]).abs().max()) <= tol, (i, it, k)
             assert float((out["trans_mat"] - r_tm).abs().max()) <= 1e-4 * float(r_tm.abs().max())
+            # (fp16 operands: three voxel levels are summed with packed-half atomics, whose rounding to 11 bits depends
+            # on the arrival order: run to run ~1e-3 of the largest entry instead of fp32's last bits)
+            vtol = 5e-3 if precision == "fp16" else 1e-4
             for a, b in zip(out["vox"], r_vox):
-                assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-12
+                assert float((a - b).abs().max()) <= vtol * float(b.abs().max()) + 1e-12
     # the forward scratch of the dead threads is back with the allocator (no grow-only per-thread cache)
     results = None
     torch.cuda.synchronize()
