@@ -225,7 +225,10 @@ int list_gather_features_fwd(const ListQueryArgs* args, float* out, void* stream
  * (lo may be NULL with LIST_PREC_BF16; with LIST_PREC_FP16 the hi planes hold fp16 and lo is
  * ignored).  M % 256 == 0, N % 256 == 0, K % 64 == 0.  relu: bit 0 = apply ReLU; bit 1 = force the plain
  * 2-stage loop instead of the ping-pong schedule that long-K single-plane products take (the two are
- * bit-identical by construction: same accumulation order -- the tests use this as a race detector).
+ * bit-identical by construction: same accumulation order -- the tests use this as a race detector);
+ * bit 2 (bf16 formats) = a_hi and w_hi hold their hi and lo halfs interleaved in 64-byte blocks, the layout the
+ * library keeps the feature matrix and the packed fc_0 weight in (element k of a row: hi at (k / 32) * 64 + k % 32,
+ * lo 32 elements further; a_lo / w_lo are ignored) -- bit-identical to the planar operands.
  */
 int list_gemm_nt(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo,
                  const float* bias, float* out, int32_t M, int32_t N, int32_t K, int32_t relu,

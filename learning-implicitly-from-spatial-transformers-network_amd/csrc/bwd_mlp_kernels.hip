@@ -62,12 +62,14 @@ __device__ __forceinline__ void stage_tn(const GemmTnParams& p, char* sbase, int
     int bcol = n0 + logical * 8;
     if (bcol > p.N - 8) bcol = p.N - 8;          // partial last tile: re-read valid columns (outputs unused)
     const int64_t aoff = ((prow0 + row) * (int64_t)p.lda + acol) * 2;
-    const int64_t boff = ((prow0 + row) * (int64_t)p.ldb + bcol) * 2;
+    // b_x3i: B is the feature matrix X with its hi / lo halfs interleaved in 64-B blocks (list_common.h xi_off)
+    const int64_t boff = p.b_x3i ? xi_off((prow0 + row) * (int64_t)p.ldb + bcol) * 2
+                                 : ((prow0 + row) * (int64_t)p.ldb + bcol) * 2;
     char* l = sbase + piece * 1024;
     glds16_tn(p.a_hi + aoff, l);
     if (TERMS == 3) glds16_tn(p.a_lo + aoff, l + P::kPlaneBytes);
     glds16_tn(p.b_hi + boff, l + P::kBOff);
-    if (TERMS == 3) glds16_tn(p.b_lo + boff, l + P::kBOff + P::kPlaneBytes);
+    if (TERMS == 3) glds16_tn((p.b_x3i ? p.b_hi + 2 * kXiLo : p.b_lo) + boff, l + P::kBOff + P::kPlaneBytes);
   }
 }
 

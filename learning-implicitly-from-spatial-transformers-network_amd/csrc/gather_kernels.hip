@@ -619,15 +619,17 @@ __global__ __launch_bounds__(256) void k_gather_tail(GatherParams g, TailLevels 
   put<FMT>(g, ro + xyz_off + 2, p.valid ? p.z : 0.f);
   // zero padding up to Kp (a multiple of 64, rows are 128-B aligned): widen the stores as the
   // alignment allows -- 6 stores instead of 38 for F = 3610 (uniform control flow: F, Kp are uniform)
+  // (split formats: hi and lo halfs interleaved in 64-B blocks, list_common.h xi_off; aligned runs of <= 8 stay inside a block)
   auto zero_pad = [&](unsigned short* __restrict__ xp) {
+    auto at = [&](int k) -> unsigned short* { return xp + (FMT == FMT_FP16 ? ro + k : xi_off(ro + k)); };
     int k = F;
-    if ((k & 1) && k < g.Kp) { xp[ro + k] = 0; k += 1; }
-    if ((k & 2) && k + 2 <= g.Kp) { *(unsigned*)(xp + ro + k) = 0u; k += 2; }
-    if ((k & 4) && k + 4 <= g.Kp) { *(uint2*)(xp + ro + k) = make_uint2(0u, 0u); k += 4; }
-    for (; k + 8 <= g.Kp; k += 8) *(uint4*)(xp + ro + k) = make_uint4(0u, 0u, 0u, 0u);
+    if ((k & 1) && k < g.Kp) { *at(k) = 0; k += 1; }
+    if ((k & 2) && k + 2 <= g.Kp) { *(unsigned*)at(k) = 0u; k += 2; }
+    if ((k & 4) && k + 4 <= g.Kp) { *(uint2*)at(k) = make_uint2(0u, 0u); k += 4; }
+    for (; k + 8 <= g.Kp; k += 8) *(uint4*)at(k) = make_uint4(0u, 0u, 0u, 0u);
   };
   zero_pad(g.x_hi);
-  if (FMT == FMT_BF16_SPLIT) zero_pad(g.x_lo);
+  if (FMT == FMT_BF16_SPLIT) zero_pad(g.x_hi + kXiLo);
 }
 
 // ---- exact redo of flagged row tiles (cold) -----------------------------------------------------------------
@@ -804,7 +806,7 @@ __global__ __launch_bounds__(256) void k_features_out(GatherParams g, FeatLayout
   const int64_t gp = g.p_begin + (g.order ? g.order[row] : row);
   const int b = (int)(gp / g.N);
   const int n = (int)(gp - (int64_t)b * g.N);
-  const float v = g.fmt == FMT_FP16 ? h2f(g.x_hi[i]) : bf2f(g.x_hi[i]) + bf2f(g.x_lo[i]);
+  const float v = g.fmt == FMT_FP16 ? h2f(g.x_hi[i]) : bf2f(g.x_hi[xi_off(i)]) + bf2f(g.x_hi[xi_off(i) + kXiLo]);
   out[((int64_t)b * L.F + kr) * g.N + n] = v;
   if (nan_tiles && v != v) nan_tiles[row / kRowTile] = 1;        // same trigger as fc_0's epilogue
 }

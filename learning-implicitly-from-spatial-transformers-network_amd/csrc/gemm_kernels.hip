@@ -587,9 +587,15 @@ __device__ __forceinline__ void pp_fence() {
 #endif
 }
 
-template <int EPI, int FP16, bool S16>
+// X3 (split formats, 16x16x32 shape only): the operands hold hi and lo halfs interleaved in 64-B blocks (xi_off), so a
+// 128-B LDS row is [32 hi | 32 lo] of a K-tile of 32 columns -- the staging, the LDS image and the fragment reads are
+// those of the single-plane kernel (k-step 0 = the hi halfs, k-step 1 = the lo halfs); only the MFMA section differs:
+// X3 == 3: acc += a_lo.w_hi + a_hi.w_lo + a_hi.w_hi (the order of the plain split kernel: bit-identical to it);
+// X3 == 1: a_hi.w_hi only (plain bf16 precision on the interleaved operands).
+template <int EPI, int FP16, bool S16, int X3 = 0>
 __global__ __launch_bounds__(512, 2) void k_gemm_nt_pp(GemmParams p) {
   using P = Pipe<1>;
+  static_assert(X3 == 0 || (S16 && !FP16), "interleaved split operands: 16x16x32 bf16 only");
   static_assert(P::BK == 64 && P::kRowBytes == 128, "single-plane pipeline");
   __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
   const int lane = threadIdx.x & 63;
@@ -621,8 +627,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_pp(GemmParams p) {
   const int fswz = P::swz(frow);               // block row offsets are multiples of 16
   const int a_row_off = (wm * 128 + frow) * P::kRowBytes;
   const int w_row_off = (wn * 64 + frow) * P::kRowBytes;
-  const int64_t ld = (int64_t)p.K * 2;
-  const int nk = p.K / P::BK;
+  const int64_t ld = (int64_t)p.K * (X3 ? 4 : 2);          // bytes per operand row
+  const int nk = X3 ? p.K / 32 : p.K / P::BK;              // K-tiles of 128 operand bytes per row
 
   // one staging quarter = 16 pieces of 1 KB (8 rows of 128 B); this wave moves pieces 2 wave and 2 wave + 1
   auto stage_quarter = [&](char* sbase, int kbyte, int quarter) {
@@ -709,7 +715,15 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_pp(GemmParams p) {
             asm volatile("" ::"v"(a[bi][ks]), "v"(w[jh][bj][ks]));
 #else
             auto& c = acc[ih * HA + bi][jh * HW + bj];
-            if constexpr (S16) c = mfma16<FP16>(a[bi][ks], w[jh][bj][ks], c);
+            if constexpr (X3 != 0) {
+              if (ks == 0) {                 // [0] = hi halfs, [1] = lo halfs of the same 32 columns
+                if constexpr (X3 == 3) {
+                  c = mfma16<0>(a[bi][1], w[jh][bj][0], c);
+                  c = mfma16<0>(a[bi][0], w[jh][bj][1], c);
+                }
+                c = mfma16<0>(a[bi][0], w[jh][bj][0], c);
+              }
+            } else if constexpr (S16) c = mfma16<FP16>(a[bi][ks], w[jh][bj][ks], c);
             else c = mfma<FP16>(a[bi][ks], w[jh][bj][ks], c);
 #endif
           }
@@ -802,6 +816,15 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt16(GemmParams p) {
 template <int TERMS, int EPI, int FP16>
 static hipError_t launch_one(const GemmParams& p, hipStream_t s) {
   const int ntiles = (p.M / BM) * (p.N / BN);
+  // interleaved split operands (fc_0's X and packed weight in the bf16 formats): always the ping-pong schedule
+  if constexpr (FP16 == 0 && (EPI == EPI_RELU_SPLIT || EPI == EPI_F32)) {
+    if (p.x3i) {
+      if constexpr (TERMS == 3) hipLaunchKernelGGL((k_gemm_nt_pp<EPI, 0, true, 3>), dim3(ntiles), dim3(512), 0, s, p);
+      else hipLaunchKernelGGL((k_gemm_nt_pp<EPI, 0, true, 1>), dim3(ntiles), dim3(512), 0, s, p);
+      return hipGetLastError();
+    }
+  }
+  if (p.x3i) return hipErrorInvalidValue;
   // MFMA shape per epilogue (measured, fp16, P = 160k): 32x32x16 has the cheaper 64-B store runs on the short-K
   // layers (fc_1 0.074 vs 0.086 ms), 16x16x32 the cheaper row reduction of the fused fc_2 + fc_out epilogue (0.045
   // vs 0.058 ms) and, on the long-K ping-pong schedule, the higher clock (fc_0 0.55 -> 0.49 ms)
@@ -826,7 +849,7 @@ static hipError_t launch_one(const GemmParams& p, hipStream_t s) {
     }
 #endif
 #ifndef LIST_X3_SHAPE32      // the hi/lo-split long-K product (fc_0 in bf16x3) on the 16x16x32 shape: 1.52 -> 1.43 ms
-    if constexpr (TERMS == 3 && EPI == EPI_RELU_SPLIT) {
+    if constexpr (TERMS == 3 && (EPI == EPI_RELU_SPLIT || EPI == EPI_F32)) {
       if (p.K >= 1024) {
         hipLaunchKernelGGL((k_gemm_nt16<TERMS, EPI, FP16>), dim3(ntiles), dim3(512), 0, s, p);
         return hipGetLastError();
@@ -855,6 +878,7 @@ static hipError_t launch_epi(const GemmParams& p, int epi, hipStream_t s) {
 
 hipError_t launch_gemm(const GemmParams& p, int terms, int epi, hipStream_t s) {
   if (p.M % BM || p.N % BN || p.K % 64 || p.M <= 0) return hipErrorInvalidValue;
+  if (p.x3i && p.fmt == FMT_FP16) return hipErrorInvalidValue;
   if (epi == EPI_RELU_DOT && p.N != BN) return hipErrorInvalidValue;
   if (p.fmt == FMT_FP16) return launch_epi<1, 1>(p, epi, s);
   if (terms == 3) return launch_epi<3, 0>(p, epi, s);

@@ -346,6 +346,10 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
     gp.w_hi = wp + pk.w0_hi; gp.w_lo = wp + pk.w0_lo;
     gp.bias = (const float*)(wp + pk.b0);
     gp.M = crow; gp.N = a->H1; gp.K = L.Kp;
+    // bf16 split formats: X and the packed fc_0 weight hold their hi / lo halfs interleaved (list_common.h xi_off)
+    gp.x3i = g.fmt == FMT_FP16 ? 0 : 1;
+    if (gp.x3i && (ws.x_lo != ws.x_hi + (size_t)rows * L.Kp * 2 || pk.w0_lo != pk.w0_hi + (size_t)a->H1 * L.Kp * 2))
+      return fail(LIST_ERR_ARG, "internal: hi / lo planes of X or of the packed fc_0 weight are not contiguous");
     gp.out_hi = (unsigned short*)(wsb + ws.h1_hi);
     gp.out_lo = terms == 3 ? (unsigned short*)(wsb + ws.h1_lo) : nullptr;
     gp.ldo = a->H1;
@@ -361,7 +365,7 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
     gp.nan_tiles = nullptr; gp.tile_gate = nan_tiles;
     e = launch_gemm(gp, terms, EPI_RELU_SPLIT, s);
     if (e != hipSuccess) return hip_fail(e, "gated fc_0 launch");
-    gp.tile_gate = nullptr;
+    gp.tile_gate = nullptr; gp.x3i = 0;
     mark(LIST_STAGE_EXACT);
     // fc_1 + ReLU
     gp.a_hi = wsb + ws.h1_hi; gp.a_lo = wsb + ws.h1_lo;
@@ -633,6 +637,7 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
     const int nk = crow / (terms == 3 ? 32 : 64);
     tp.steps_per_split = (nk + tp.splits - 1) / tp.splits;
     tp.slab = slab; tp.ldn = N; tp.fmt = fmt;
+    tp.b_x3i = (layout && !fp16) ? 1 : 0;          // B = X: hi / lo halfs interleaved in the split formats
     hipError_t err = launch_gemm_tn(tp, terms, s);
     if (err != hipSuccess) return err;
     return launch_wgrad_reduce(slab, tp.splits, M, N, N, layout, scale, out, ldo, s);
@@ -839,6 +844,8 @@ int list_gemm_nt(const void* a_hi, const void* a_lo, const void* w_hi, const voi
   gp.w_hi = (const char*)w_hi; gp.w_lo = (const char*)w_lo;
   gp.bias = bias; gp.M = M; gp.N = N; gp.K = K; gp.out_f32 = out; gp.relu = relu & 1;
   gp.plain_loop = (relu & 2) ? 1 : 0;
+  gp.x3i = (relu & 4) ? 1 : 0;                     // a_hi / w_hi hold hi and lo interleaved (bf16 formats only)
+  if (gp.x3i && precision == LIST_PREC_FP16) return fail(LIST_ERR_ARG, "interleaved operands are a bf16-format layout");
   gp.fmt = precision == LIST_PREC_FP16 ? FMT_FP16 : FMT_BF16_SPLIT;
   hipError_t e = launch_gemm(gp, precision == LIST_PREC_BF16X3 ? 3 : 1, EPI_F32, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "gemm launch");

@@ -85,7 +85,16 @@ __device__ __forceinline__ uint2 half4_inrange(const float4& v) {
 __device__ __forceinline__ float relu_nan(float x) { return x < 0.f ? 0.f : x; }
 enum { FMT_BF16_SPLIT = 0, FMT_FP16 = 1 };     // element format of X / H / packed weights
 
-// store 4 consecutive features of one row
+// ---- hi / lo planes of the long-K operands (X and the packed fc_0 weight), bf16 split formats ----------------
+// The two planes are INTERLEAVED in 64-byte blocks: element `off` (= row * Kp + column, Kp % 32 == 0) has its hi half
+// at xi_off(off) and its lo half 32 elements further, so the 32 hi and 32 lo halfs of a 32-column block are one
+// 128-byte line.  fc_0 then stages a K-tile of 32 columns as full lines (separate planes gave 64-B half-line
+// LDS-DMA segments, which cap the L2 -> LDS rate) into the same LDS image the single-plane schedule uses.  The
+// region is the former [hi plane | lo plane] pair, which must be contiguous.  fp16 (one plane) is not affected.
+__device__ __forceinline__ int64_t xi_off(int64_t off) { return ((off >> 5) << 6) | (off & 31); }
+constexpr int kXiLo = 32;                      // elements from a hi half to its lo half
+
+// store 4 consecutive features of one row (off % 4 == 0)
 template <int FMT>
 __device__ __forceinline__ void store_feat4(unsigned short* x_hi, unsigned short* x_lo, int64_t off,
                                             const float4& v) {
@@ -98,8 +107,10 @@ __device__ __forceinline__ void store_feat4(unsigned short* x_hi, unsigned short
   } else {
     uint2 hi, lo;
     split4(v, hi, lo);
-    __builtin_nontemporal_store((u32x2){hi.x, hi.y}, (u32x2*)(x_hi + off));
-    __builtin_nontemporal_store((u32x2){lo.x, lo.y}, (u32x2*)(x_lo + off));
+    (void)x_lo;
+    unsigned short* d = x_hi + xi_off(off);
+    __builtin_nontemporal_store((u32x2){hi.x, hi.y}, (u32x2*)d);
+    __builtin_nontemporal_store((u32x2){lo.x, lo.y}, (u32x2*)(d + kXiLo));
   }
 }
 template <int FMT>
@@ -109,8 +120,9 @@ __device__ __forceinline__ void store_feat1(unsigned short* x_hi, unsigned short
     x_hi[off] = f2h(v);
   } else {
     const unsigned short h = f2bf(v);
-    x_hi[off] = h;
-    x_lo[off] = bf_lo(v, h);
+    (void)x_lo;
+    x_hi[xi_off(off)] = h;
+    x_hi[xi_off(off) + kXiLo] = bf_lo(v, h);
   }
 }
 
@@ -341,6 +353,7 @@ struct GemmParams {
   int plain_loop;                                            // diagnostics: never take the ping-pong schedule
   int* nan_tiles;                                            // EPI_RELU_SPLIT: nan_tiles[m0 / 256] = 1 if the tile's output holds a NaN
   const int* tile_gate;                                      // run only the row tiles with tile_gate[m0 / 256] != 0
+  int x3i;                                                   // split formats: a_hi / w_hi hold hi and lo interleaved (xi_off); a_lo / w_lo unused
 };
 
 // EPI_MASK_SPLIT: out = acc where the saved activation is positive (ReLU backward), no bias;
@@ -355,6 +368,7 @@ struct GemmTnParams {
   int splits, steps_per_split;                     // K-steps (of BK rows) per split
   float* slab; int ldn;                            // [splits][M][ldn] fp32
   int fmt;
+  int b_x3i;                                       // split formats: b_hi holds hi and lo interleaved (xi_off: the X operand); b_lo unused
 };
 
 // ---- launchers (defined in the .hip files) ----------------------------------------------------

@@ -669,8 +669,9 @@ __global__ __launch_bounds__(256) void k_prep_w0(const float* __restrict__ w0, F
   const float v = kr >= 0 ? w0[(int64_t)n * L.F + kr] : 0.f;
   if (fmt == FMT_FP16) { hi[i] = f2h(v); return; }
   const unsigned short h = f2bf(v);
-  hi[i] = h;
-  lo[i] = bf_lo(v, h);
+  (void)lo;                                   // split formats: hi / lo halfs interleaved in 64-B blocks (xi_off)
+  hi[xi_off(i)] = h;
+  hi[xi_off(i) + kXiLo] = bf_lo(v, h);
 }
 
 __global__ __launch_bounds__(256) void k_split(const float4* __restrict__ x, uint2* __restrict__ hi,

@@ -703,9 +703,19 @@ def to_fp16(x):
     return out
 
 
-def gemm_nt(a, w, bias=None, relu=False, precision="bf16x3", plain_loop=False):
+def interleave_planes(hi, lo):
+    """[R,K] hi / lo bf16 planes -> the interleaved layout of X and the packed fc_0 weight: per row and 32-column
+    block, 32 hi halfs then 32 lo halfs (one 128-byte line)."""
+    R, K = hi.shape
+    if K % 32:
+        raise RuntimeError("K must be a multiple of 32")
+    return torch.stack((hi.reshape(R, K // 32, 32), lo.reshape(R, K // 32, 32)), dim=2).reshape(R, 2 * K).contiguous()
+
+
+def gemm_nt(a, w, bias=None, relu=False, precision="bf16x3", plain_loop=False, interleaved=False):
     """Diagnostic: out[M,N] = act(a[M,K] @ w[N,K]^T + bias) through the MLP's MFMA kernel.
-    plain_loop: force the 2-stage loop where the ping-pong schedule would be taken."""
+    plain_loop: force the 2-stage loop where the ping-pong schedule would be taken.
+    interleaved (bf16 formats): hand the operands over in the hi / lo interleaved layout fc_0 reads."""
     lib = load()
     M, K = a.shape
     N = w.shape[0]
@@ -715,11 +725,15 @@ def gemm_nt(a, w, bias=None, relu=False, precision="bf16x3", plain_loop=False):
     else:
         a_hi, a_lo = split_bf16(a)
         w_hi, w_lo = split_bf16(w)
+        if interleaved:
+            a_hi = a_lo = interleave_planes(a_hi, a_lo)
+            w_hi = w_lo = interleave_planes(w_hi, w_lo)
     out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     b = _f32_cuda(bias, "bias").contiguous() if bias is not None else None
     with torch.cuda.device(a.device):
         _check(lib.list_gemm_nt(a_hi.data_ptr(), a_lo.data_ptr(), w_hi.data_ptr(), w_lo.data_ptr(),
                                 b.data_ptr() if b is not None else None, out.data_ptr(), M, N, K,
-                                int(relu) | (2 if plain_loop else 0), PRECISIONS[precision], _stream()),
+                                int(relu) | (2 if plain_loop else 0) | (4 if interleaved and precision != "fp16" else 0),
+                                PRECISIONS[precision], _stream()),
                "list_gemm_nt")
     return out

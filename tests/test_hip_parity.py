@@ -97,6 +97,21 @@ def test_pingpong_schedule_is_bit_identical_to_the_plain_loop(hip):
                 assert torch.equal(x, y), (rep, M, N, K, prec)
 
 
+def test_interleaved_split_operands_are_bit_identical_to_the_planes(hip):
+    """fc_0 reads X and its packed weight with the bf16 hi / lo halfs interleaved in 64-byte blocks (full-line
+    LDS-DMA rows) on the ping-pong schedule; the products and their order are those of the plain split kernel on
+    separate planes, so the two must agree bit for bit (layout bug or race otherwise), with and without bias / ReLU."""
+    for rep in range(4):
+        for (M, N, K) in [(256, 256, 1024), (512, 512, 3648), (1024, 256, 2048), (768, 512, 1088)]:
+            a = synth.normalish(300 + rep, (M, K))
+            w = synth.uniform(400 + rep, (N, K), -0.05, 0.05)
+            b = synth.uniform(500 + rep, (N,), -0.1, 0.1)
+            for prec in ("bf16x3", "bf16"):
+                x = hip.gemm_nt(dev(a), dev(w), dev(b), relu=bool(rep & 1), precision=prec)
+                y = hip.gemm_nt(dev(a), dev(w), dev(b), relu=bool(rep & 1), precision=prec, interleaved=True)
+                assert torch.equal(x, y), (rep, M, N, K, prec)
+
+
 def test_gemm_kernel_identity_asymmetric(hip):
     """A = I against an asymmetric W catches a transposed C-write or a wrong k-order."""
     K = N = 256
