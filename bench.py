@@ -346,8 +346,9 @@ def roofline_of(kernel_ms, table, precision, workload):
     secs = kernel_ms[dom] * 1e-3
     traffic = pmc_traffic(precision, workload).get(dom)
     ach = units / secs / 1e12
-    fc0 = "k_gemm_nt (fc_0 + ReLU)" if precision == "bf16x3" else "k_gemm_nt_pp (fc_0 + ReLU)"
-    r = {"kernel": {"fc_0": fc0, "fc_1": "k_gemm_nt (fc_1 + ReLU)",
+    # fc_0 runs the ping-pong schedule in every precision (single plane, or hi / lo interleaved for the split formats)
+    fc1 = "k_gemm_nt (fc_1 + ReLU)" if precision == "bf16x3" else "k_gemm_nt_pp (fc_1 + ReLU)"
+    r = {"kernel": {"fc_0": "k_gemm_nt_pp (fc_0 + ReLU)", "fc_1": fc1,
                     "fc_2_out": "k_gemm_nt16 (fc_2 + ReLU + fc_out)"}[dom],
          "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
          "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "launches_per_step": launches,

@@ -25,8 +25,8 @@ def kernel_key(name, grid, seq):
     if not m:
         return None
     k, t = m.group(1), (m.group(2) or "")
-    if k == "k_gemm_nt_pp":                   # long-K single-plane products: fc_0
-        return "fc_0"
+    if k == "k_gemm_nt_pp":                   # ping-pong schedule: fc_0 (1250 tiles) and, in fp16, fc_1 (625 tiles)
+        return "fc_0" if grid >= 600000 else "fc_1"
     if k in ("k_gemm_nt", "k_gemm_nt16"):
         epi = t.strip("<>").split(",")[1].strip()
         if epi == "2":
