@@ -352,15 +352,6 @@ def release_workspaces():
         _aux_pool.clear()
 
 
-def _query_ws_bytes(lib, n_points, F, H1, H2, H3, private):
-    # LIST_WS_ROWS (diagnostic): a workspace sized for fewer rows makes list_sdf_query_fwd cut the query into
-    # smaller row chunks (bit-identical results); a forward saved for the backward always gets the full size
-    rows = int(os.environ.get("LIST_WS_ROWS", "0"))
-    if rows > 0 and not private:
-        n_points = min(n_points, rows)
-    return lib.list_query_workspace_bytes(n_points, F, H1, H2, H3)
-
-
 def _fill_query_args(query, perm, scale, vox, packed, precision, trans_mat=None, img=None,
                      percep_feat=None, clamp_hi=136.0, private_workspace=False):
     lib = load()
@@ -400,7 +391,7 @@ def _fill_query_args(query, perm, scale, vox, packed, precision, trans_mat=None,
     if (a.precision == PREC_FP16) != bool(packed.fp16):
         raise RuntimeError("packed MLP weights were prepared for a different precision "
                            "(fp16 vs bf16 planes); call prep_mlp_weights(..., precision=...) again")
-    nbytes = _query_ws_bytes(lib, B * N, a.F, a.H1, a.H2, a.H3, private_workspace)
+    nbytes = lib.list_query_workspace_bytes(B * N, a.F, a.H1, a.H2, a.H3)
     # a call whose backward will run later keeps its own workspace (X, H1, H2, point order live there)
     ws = (torch.empty((nbytes,), dtype=torch.uint8, device=query.device) if private_workspace
           else _workspace(query.device, nbytes))
@@ -412,7 +403,7 @@ def _fill_query_args(query, perm, scale, vox, packed, precision, trans_mat=None,
 def query_chunks(n_points, packed):
     """Row chunks list_sdf_query_fwd cuts a query of n_points into (with the workspace sdf_query gives it)."""
     lib = load()
-    nbytes = _query_ws_bytes(lib, n_points, packed.F, packed.H1, packed.H2, packed.H3, False)
+    nbytes = lib.list_query_workspace_bytes(n_points, packed.F, packed.H1, packed.H2, packed.H3)
     rows = lib.list_query_chunk_rows(nbytes, n_points, packed.F, packed.H1, packed.H2, packed.H3)
     if rows <= 0:
         raise RuntimeError("list_query_chunk_rows failed")
