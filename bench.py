@@ -91,8 +91,10 @@ def make_inputs(workload, rank, device):
         trans = trans * (map_size - 1) / 136.0
         trans[:, :, 2] = trans[:, :, 2] * 136.0 / (map_size - 1)
     weights = {k: torch.from_numpy(v).to(device) for k, v in synth.make_mlp_weights(333).items()}
+    # the inference grid arrives in raster order: executors.LIST.predict_grid asks for ordered_points (no point sort)
     return dict(B=B, N=N, img_maps=img_maps, vox_maps=vox_maps, query=query, trans_mat=trans,
-                weights=weights, map_size=map_size, clamp_hi=clamp_hi)
+                weights=weights, map_size=map_size, clamp_hi=clamp_hi,
+                ordered_points=workload.startswith("list_grid"))
 
 
 # Algorithmic work per query point of every kernel (bytes for the HBM-bound gathers and
@@ -167,7 +169,8 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
         packed = hip.prep_mlp_weights(inp["weights"], vox.channels, img.channels, precision)
         if pre: ev.record(pre[3])
         hip.sdf_query(inp["query"], inp["trans_mat"], img, vox, packed, precision=precision,
-                      out=sdf, stage_events=arr, clamp_hi=inp["clamp_hi"])
+                      out=sdf, stage_events=arr, clamp_hi=inp["clamp_hi"],
+                      sort_points=not inp.get("ordered_points", False))
         if world > 1:
             if overlap_exchange[0]:
                 try:
@@ -582,6 +585,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": args.workload, "images_per_gpu": B, "points_per_image": N,
                    "global_points_per_step": world * P, "precision": headline,
+                   "point_sort": ("skipped: raster-ordered grid, as executors.LIST.predict_grid queries it"
+                                  if inp.get("ordered_points") else "Morton + pixel counting sort inside the step"),
                    "mlp_arithmetic": arith[headline],
                    "gather_arithmetic": "fp32 interpolation; prepared maps stored as "
                                         + ("fp16" if hip.map_dtype_for(headline) == "f16" else "fp32"),

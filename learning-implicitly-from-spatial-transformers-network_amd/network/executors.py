@@ -122,7 +122,8 @@ class LIST:
         for s in range(begin, end, self.test_pointnum):
             e = min(s + self.test_pointnum, end)
             pts = utils.grid_points_on_device(-0.5, 0.5, res, dev, s, e).unsqueeze(0)
-            out[s - begin:e - begin] = net.query_sdf(pts, feat_l2, vox_feat, transmat)[0]
+            # (raster order: consecutive grid points are neighbours already, the forward skips its point sort)
+            out[s - begin:e - begin] = net.query_sdf(pts, feat_l2, vox_feat, transmat, ordered_points=True)[0]
         if world > 1:
             out = parallel.gather_ragged_points(out, total)
         return (out / self.sdf_scale).view(res, res, res), occ, vox_feat

@@ -78,9 +78,9 @@ class LIST(nn.Module):
         return feat_l2, vox_feat, trans_mat, pc, occ
 
     # ---- per-point stage: the HIP hot path ------------------------------------------------------------
-    def query_sdf(self, query, feat_l2, vox_feat, trans_mat):
+    def query_sdf(self, query, feat_l2, vox_feat, trans_mat, ordered_points=False):
         return self.sdf_decoder.query(query, feat_l2, trans_mat, vox_feat,
-                                      map_size=self.percep_pooling.map_size)
+                                      map_size=self.percep_pooling.map_size, ordered_points=ordered_points)
 
     def forward(self, img, query, trans_mat=None):
         feat_l2, vox_feat, trans_mat, _, _ = self.encode(img, trans_mat)

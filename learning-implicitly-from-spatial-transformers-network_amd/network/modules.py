@@ -90,12 +90,13 @@ class VoxelDecoder2(VoxelDecoder):
         return hotpath.sdf_query(p, None, None, feat, self.mlp_params(), perm=(0, 1, 2), scale=1.0,
                                  precision=self.precision, percep_feat=percep_feat, caches=self._caches)
 
-    def query(self, query, img_featuremaps, trans_mat, feat, map_size=137, perm=(2, 1, 0), scale=2.0):
+    def query(self, query, img_featuremaps, trans_mat, feat, map_size=137, perm=(2, 1, 0), scale=2.0,
+              ordered_points=False):
         """Fused PerceptualPooling + VoxelDecoder2 on RAW queries (reference models.py:91-97) without
-        materialising the [B,1024,N] perceptual tensor."""
+        materialising the [B,1024,N] perceptual tensor.  ordered_points: see hotpath.sdf_query."""
         return hotpath.sdf_query(query, trans_mat, img_featuremaps, feat, self.mlp_params(), perm=perm,
                                  scale=scale, map_size=map_size, precision=self.precision,
-                                 caches=self._caches)
+                                 caches=self._caches, ordered_points=ordered_points)
 
 
 # ======================================================================================= per-image modules
