@@ -161,6 +161,8 @@ typedef struct ListQueryArgs {
                                         /*   stage boundaries below; set c belongs to row chunk c   */
   int32_t no_sort;                      /* 0: process points in Morton order (default; results are  */
                                         /*   bit-identical either way), 1: keep the caller's order  */
+                                        /*   -- for queries that are spatially coherent already (a  */
+                                        /*   raster grid: the sort is ~6 % of such a query's time)  */
   int32_t stage_event_sets;             /* number of event sets behind stage_events (0 counts as 1): */
                                         /*   row chunk c records into set c, chunks beyond the last  */
                                         /*   set record nothing.  list_query_chunk_rows() tells how  */
