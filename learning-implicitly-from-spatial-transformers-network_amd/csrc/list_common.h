@@ -138,7 +138,7 @@ __device__ __forceinline__ int xcd_contiguous_block(int bid, int nblocks) {
 
 // ---- feature layout ---------------------------------------------------------------------
 // Column order of the gathered feature matrix X[row][Kp] ("gather order"):
-//   [vector voxel levels (C%4==0): level-major, stencil j, channel c]  [perceptual img_C]
+//   [perceptual img_C]  [vector voxel levels (C%4==0): level-major, stencil j, channel c]
 //   [scalar voxel levels (C==1): stencil j]  [xyz]  [zero pad to a multiple of kKTile]
 // The reference order (network/modules.py:270-275) is k = (cbase_L + c)*7 + j | img | xyz;
 // fc_0's columns are permuted once (list_prep_mlp_weights) so no shuffle happens per point.
@@ -164,10 +164,12 @@ inline bool make_layout(const int32_t vox_C[LIST_N_VOX_LEVELS], int32_t img_C, F
     cbase += C;
   }
   L->vox_ctotal = cbase;
-  for (int l = 0; l < LIST_N_VOX_LEVELS; ++l)
-    if (L->vox_C[l] != 1) { L->vox_off[l] = col; col += LIST_N_STENCIL * L->vox_C[l]; }
+  // the perceptual block comes FIRST: fc_0 can then leave it out by starting its K loop at column img_C (inference
+  // with a projected perceptual map, list_prep_percep_proj) without splitting a K-tile
   if (img_C < 0 || (img_C % 4) != 0) return false;
   L->img_off = col; L->img_C = img_C; col += img_C;
+  for (int l = 0; l < LIST_N_VOX_LEVELS; ++l)
+    if (L->vox_C[l] != 1) { L->vox_off[l] = col; col += LIST_N_STENCIL * L->vox_C[l]; }
   for (int l = 0; l < LIST_N_VOX_LEVELS; ++l)
     if (L->vox_C[l] == 1) { L->vox_off[l] = col; col += LIST_N_STENCIL; }
   L->xyz_off = col; col += 3;
