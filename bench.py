@@ -102,7 +102,7 @@ def make_inputs(workload, rank, device):
 VOX_C = [1, 16, 32, 64, 128, 128]
 
 
-def kernel_table(B, N, img_res, vox_res, map_size, x_bytes_per_feature, map_bytes=4):
+def kernel_table(B, N, img_res, vox_res, map_size, x_bytes_per_feature, map_bytes=4, proj=False):
     """name -> (bound, algorithmic units per step, what the units are).
     Layout kernels: HBM bytes that must move (source read once + prepared map written once).
     MFMA kernels: SURVEY 8d FLOPs (K = 3610, not the padded K).
@@ -115,12 +115,18 @@ def kernel_table(B, N, img_res, vox_res, map_size, x_bytes_per_feature, map_byte
     vox_elems = [int(np.prod(s)) for s in synth.vox_map_shapes(B, vox_res)]
     img_elems_in = sum(int(np.prod(s)) for s in synth.img_map_shapes(B, img_res))
     img_elems_out = B * map_size * map_size * 1024
+    # proj (inference grid, list_prep_percep_proj): the perceptual block of fc_0 is applied to the map once per image;
+    # the per-point sample reads 4 taps of 512 projected channels and fc_0 runs K = 3610 - 1024 columns: the FLOPs and
+    # bytes below are what the kernels then execute
+    k0 = 3610 - 1024 if proj else 3610
+    img_tap = 512 * map_bytes if proj else 1024 * map_bytes
+    img_x = 512 * 4 if proj else 1024 * x_bytes_per_feature
     t = {
         "prep_img_resize_nhwc": ("hbm", 4 * img_elems_in + map_bytes * img_elems_out, "bytes moved"),
         "prep_vox_ndhwc": ("hbm", (4 + map_bytes) * sum(vox_elems[1:]), "bytes moved"),
-        "gather_img": ("l2", P * (4 * 1024 * map_bytes + 1024 * x_bytes_per_feature + 12), "tap + X bytes requested"),
+        "gather_img": ("l2", P * (4 * img_tap + img_x + 12), "tap + X bytes requested"),
         "gather_tail": ("l2", P * (7 * 8 * 4 + 48 * x_bytes_per_feature), "tap + X bytes requested"),
-        "fc_0": ("mfma", P * 2 * 3610 * 512, "FLOP"),
+        "fc_0": ("mfma", P * 2 * k0 * 512, "FLOP"),
         "fc_1": ("mfma", P * 2 * 512 * 256, "FLOP"),
         "fc_2_out": ("mfma", P * 2 * (256 * 256 + 256), "FLOP"),
     }
@@ -167,10 +173,13 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
         vox = hip.prep_vox_maps(inp["vox_maps"], md)
         if pre: ev.record(pre[2])
         packed = hip.prep_mlp_weights(inp["weights"], vox.channels, img.channels, precision)
+        # inference grid (executors.LIST.predict_grid): many points on one image -- the perceptual block of fc_0 is
+        # applied to the 137^2 map once (inside the timed step, counted with prep_weights) and sampled per point
+        proj = hip.prep_percep_proj(img, packed, precision) if inp.get("ordered_points") else None
         if pre: ev.record(pre[3])
         hip.sdf_query(inp["query"], inp["trans_mat"], img, vox, packed, precision=precision,
                       out=sdf, stage_events=arr, clamp_hi=inp["clamp_hi"],
-                      sort_points=not inp.get("ordered_points", False))
+                      sort_points=not inp.get("ordered_points", False), percep_proj=proj)
         if world > 1:
             if overlap_exchange[0]:
                 try:
@@ -484,12 +493,13 @@ def main():
     value = world * P * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
     xb = 2 if headline != "bf16x3" else 4
-    table = kernel_table(B, N, img_res, vox_res, map_size, xb, 2 if headline == "fp16" else 4)
+    table = kernel_table(B, N, img_res, vox_res, map_size, xb, 2 if headline == "fp16" else 4, proj=bool(inp.get("ordered_points")))
     roof = roofline_of(kernel_ms, table, headline, args.workload)
     if alt is not None:
         a16 = alt["precision"] == "fp16"
         alt["roofline"] = roofline_of(alt["kernel_ms"], kernel_table(B, N, img_res, vox_res, map_size, 2 if a16 else 4,
-                                                                      2 if a16 else 4), alt["precision"], args.workload)
+                                                                      2 if a16 else 4, proj=bool(inp.get("ordered_points"))),
+                                      alt["precision"], args.workload)
         alt["path_roofs"] = path_roofs(alt["value"] / world, alt["precision"])
     gather_ms = sum(v for k, v in kernel_ms.items() if k.startswith("gather_"))
     mlp_ms = kernel_ms["fc_0"] + kernel_ms["fc_1"] + kernel_ms["fc_2_out"]
@@ -587,6 +597,9 @@ def main():
                    "global_points_per_step": world * P, "precision": headline,
                    "point_sort": ("skipped: raster-ordered grid, as executors.LIST.predict_grid queries it"
                                   if inp.get("ordered_points") else "Morton + pixel counting sort inside the step"),
+                   "perceptual_block": ("projected through fc_0 once per image (list_prep_percep_proj, inside the step), "
+                                        "sampled per point; fc_0 runs the other 2586 columns"
+                                        if inp.get("ordered_points") else "1024 sampled features per point in fc_0's K"),
                    "mlp_arithmetic": arith[headline],
                    "gather_arithmetic": "fp32 interpolation; prepared maps stored as "
                                         + ("fp16" if hip.map_dtype_for(headline) == "f16" else "fp32"),

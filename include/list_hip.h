@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LIST_ABI_VERSION 4
+#define LIST_ABI_VERSION 5
 
 #define LIST_N_IMG_LEVELS 5   /* ResEncoder feature maps, network/modules.py:1067 */
 #define LIST_N_VOX_LEVELS 6   /* VoxelEncoder2 feature maps, network/modules.py:425-442 */
@@ -131,6 +131,26 @@ size_t list_packed_mlp_bytes(const ListMlpWeights* w);
 int list_prep_mlp_weights(const ListMlpWeights* w, void* packed, size_t packed_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * list_prep_percep_proj -- inference with many query points per image (a marching-cubes grid,
+ * network/executors.py:191-231): fc_0 is linear, so the contribution of the perceptual block of
+ * the feature vector (modules.py:46-53: bilinear samples of the prepared map) to fc_0's
+ * pre-activation equals the bilinear sample of the PROJECTED map
+ *   proj[b][y][x][n] = sum_c img_map[b][y][x][c] * fc_0.weight[n][perceptual column c]
+ * -- one [B*map_size^2, img_C] x [img_C, H1] product per image instead of img_C columns of fc_0 per
+ * query point.  Same arithmetic class as the MLP (operand format of `precision`, fp32 accumulate);
+ * the projected map is fp16 for LIST_PREC_FP16 (img_map must be LIST_MAP_F16) and fp32 for the bf16
+ * formats (img_map must be LIST_MAP_F32; `scratch` then holds its bf16 hi/lo copy).  Valid while
+ * img_map and packed_mlp stay unchanged.  Finite maps: the exact border / non-finite semantics of the
+ * standard path are per feature and are not reproduced tap by tap here.
+ */
+size_t list_percep_proj_bytes(int32_t B, int32_t map_size, int32_t H1, int32_t precision);
+size_t list_percep_proj_scratch_bytes(int32_t B, int32_t map_size, int32_t img_C, int32_t precision);
+int list_prep_percep_proj(const void* img_map, int32_t img_dtype, int32_t B, int32_t map_size,
+                          const int32_t vox_C[LIST_N_VOX_LEVELS], int32_t img_C, const void* packed_mlp,
+                          int32_t H1, int32_t H2, int32_t H3, int32_t precision, void* proj,
+                          size_t proj_bytes, void* scratch, size_t scratch_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * list_sdf_query_fwd -- the fused hot path: LIST.forward lines network/models.py:91-97, i.e.
  * PerceptualPooling.forward (modules.py:37-53, on the prepared 137^2 map) +
  * VoxelDecoder2.forward (modules.py:255-282).  sdf[b][n] for every query point.
@@ -167,6 +187,13 @@ typedef struct ListQueryArgs {
                                         /*   row chunk c records into set c, chunks beyond the last  */
                                         /*   set record nothing.  list_query_chunk_rows() tells how  */
                                         /*   many chunks a call takes                                */
+  const void* percep_proj;              /* optional (ABI 5, inference): output of                    */
+                                        /*   list_prep_percep_proj for img_map and packed_mlp.  The  */
+                                        /*   perceptual block of fc_0 is then taken from it (one     */
+                                        /*   4-tap sample of H1 channels per point) and fc_0 skips   */
+                                        /*   that block; img_map is still required (its descriptor   */
+                                        /*   fields are checked), percep_feat must be NULL, and the  */
+                                        /*   call cannot be followed by list_sdf_query_bwd           */
 } ListQueryArgs;
 
 /* Boundaries recorded into ListQueryArgs.stage_events: one hipEvent after each kernel (group) of a

@@ -479,7 +479,10 @@ __device__ __forceinline__ void reduce_proj_exact(const typename M::Raw (&v)[4],
   tap_fma_masked<M>(v[2], pr.w10, (pr.dead >> 2) & 1, r); tap_fma_masked<M>(v[3], pr.w11, (pr.dead >> 3) & 1, r);
 }
 
-template <int FMT, int F16>
+// OUT32 (projected perceptual map, list_prep_percep_proj): the map holds H1 channels per pixel and the sample is
+// written as an fp32 row vector into the first bytes of the point's X row -- the perceptual block of X, which fc_0
+// then leaves out of its K loop and adds in its epilogue instead.  Out-of-map taps are masked like the reference.
+template <int FMT, int F16, int OUT32 = 0>
 __global__ __launch_bounds__(256) void k_gather_img(GatherParams g, const void* __restrict__ img_map,
                                                     const float* __restrict__ trans_mat, int ms,
                                                     int Ct, float clamp_hi, int col_off) {
@@ -537,6 +540,15 @@ __global__ __launch_bounds__(256) void k_gather_img(GatherParams g, const void* 
         if (pi >= kGatherRows) continue;
         const ImgPoint& a = ipt[pi];
         float r[M::V];
+        if constexpr (OUT32) {
+          reduce_proj_exact<M>(v[k], a.pr, r);
+          float* dst = (float*)((char*)xh + (int64_t)a.row * g.Kp * (FMT == FMT_FP16 ? 2 : 4)) + q * M::V;
+#pragma unroll
+          for (int h = 0; h < M::V / 4; ++h)
+            *(float4*)(dst + 4 * h) = a.valid ? make_float4(r[4 * h], r[4 * h + 1], r[4 * h + 2], r[4 * h + 3])
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+          continue;
+        }
         tap_mul<M>(v[k][0], a.pr.w00, r); tap_fma<M>(v[k][1], a.pr.w01, r);
         tap_fma<M>(v[k][2], a.pr.w10, r); tap_fma<M>(v[k][3], a.pr.w11, r);
         store_feats<FMT, M::V>(xh, xl, (int64_t)a.row * g.Kp + col_off + q * M::V, r, a.valid != 0);
@@ -707,7 +719,7 @@ hipError_t launch_gather_fixup(const GatherParams& g, const FeatLayout& L, const
   fa.n = 0;
   for (int l = 0; l < LIST_N_VOX_LEVELS; ++l)
     if (a.vox[l].C != 1) { fa.lv[fa.n] = a.vox[l]; fa.off[fa.n] = L.vox_off[l]; ++fa.n; }
-  fa.img_map = a.percep_feat ? nullptr : a.img_map;
+  fa.img_map = (a.percep_feat || a.percep_proj) ? nullptr : a.img_map;     // (the projected sample is masked already)
   fa.trans_mat = a.trans_mat; fa.img_f16 = a.img_dtype == LIST_MAP_F16; fa.ms = a.map_size; fa.Ct = L.img_C;
   fa.img_off = L.img_off; fa.clamp_hi = a.clamp_hi; fa.tile_flags = tile_flags;
   if (g.fmt == FMT_FP16)
@@ -770,7 +782,14 @@ static hipError_t launch_gather_fmt(const GatherParams& g, const FeatLayout& L, 
     ++vec_level;
   }
   for (; vec_level < 5; ++vec_level) mark(LIST_STAGE_VOX0 + vec_level);
-  if (a.percep_feat) {
+  if (a.percep_proj) {          // projected perceptual map: H1 channels, fp16 (fp16 operands) or fp32
+    if (FMT == FMT_FP16)
+      hipLaunchKernelGGL((k_gather_img<FMT, 1, 1>), dim3(g.rows / kGatherRows), dim3(256), 0, s, g, a.percep_proj,
+                         a.trans_mat, a.map_size, a.H1, a.clamp_hi, 0);
+    else
+      hipLaunchKernelGGL((k_gather_img<FMT, 0, 1>), dim3(g.rows / kGatherRows), dim3(256), 0, s, g, a.percep_proj,
+                         a.trans_mat, a.map_size, a.H1, a.clamp_hi, 0);
+  } else if (a.percep_feat) {
     hipLaunchKernelGGL(k_copy_percep<FMT>, dim3((g.rows + 255) / 256), dim3(256), 0, s, g,
                        a.percep_feat, a.pf_sb, a.pf_sc, a.pf_sn, L.img_C, L.img_off);
   } else if (a.img_dtype == LIST_MAP_F16) {

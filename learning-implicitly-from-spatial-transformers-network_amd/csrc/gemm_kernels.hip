@@ -439,6 +439,55 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4v (&ac
     const int64_t row_base = m0 + wm * 128;
     const int col_base = n0 + wn * 64;
     bool bad = false;
+    if (p.rowvec) {
+      // the perceptual block's contribution, sampled from the projected map into the head of every X row: the same
+      // turns as staged_epilogue16, with the row vectors of turn c + 1 requested while turn c is processed (they
+      // come from HBM with a 7-KB row stride; fetched where they are used they cost a dependent round trip per
+      // 32 rows: +14 us per tile)
+      float* tile = (float*)smem + wave * (32 * kStageLd);
+      const int rr = lane >> 3, c8 = (lane & 7) * 8;
+      const float4 b0 = p.bias ? *(const float4*)(p.bias + col_base + c8) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 b1 = p.bias ? *(const float4*)(p.bias + col_base + c8 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      float4 rv[2][4][2];
+      auto load_rv = [&](int c, int buf) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float* src = (const float*)(p.rowvec + (row_base + c * 32 + rr + 8 * k) * p.rowvec_stride) + col_base + c8;
+          rv[buf][k][0] = *(const float4*)src;
+          rv[buf][k][1] = *(const float4*)(src + 4);
+        }
+      };
+      load_rv(0, 0);
+      __syncthreads();                                 // every wave is done with the operand stages
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (c + 1 < 4) load_rv(c + 1, (c + 1) & 1);
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              tile[(ii * 16 + row_in + e) * kStageLd + j * 16 + col_in] = acc[2 * c + ii][j][e];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int r = rr + 8 * k;
+          const float4 a = *(const float4*)(tile + r * kStageLd + c8);
+          const float4 b = *(const float4*)(tile + r * kStageLd + c8 + 4);
+          const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+          const float4 r0 = rv[c & 1][k][0], r1 = rv[c & 1][k][1];
+          const float ad[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+          float o[8];
+          // (acc + row vector) + bias: the K sum first, like the reference's fc_0
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { o[e] = relu_nan((v[e] + ad[e]) + bb[e]); bad = bad || (o[e] != o[e]); }
+          store8_planes<FP16>(p.out_hi, p.out_lo, (row_base + c * 32 + r) * p.ldo + col_base + c8, o);
+        }
+        __syncthreads();
+      }
+    } else
     staged_epilogue16(acc, smem, wave, lane, [&](int r, int c8, const float (&v)[8]) {
       float o[8];
       const float4 b0 = p.bias ? *(const float4*)(p.bias + col_base + c8) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -627,7 +676,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_pp(GemmParams p) {
   const int fswz = P::swz(frow);               // block row offsets are multiples of 16
   const int a_row_off = (wm * 128 + frow) * P::kRowBytes;
   const int w_row_off = (wn * 64 + frow) * P::kRowBytes;
-  const int64_t ld = (int64_t)p.K * (X3 ? 4 : 2);          // bytes per operand row
+  const int64_t lda = (int64_t)(p.lda ? p.lda : p.K) * (X3 ? 4 : 2);      // bytes per operand row
+  const int64_t ldw = (int64_t)(p.ldw ? p.ldw : p.K) * (X3 ? 4 : 2);
+  const int a_last = (p.a_rows ? p.a_rows : p.M) - 1;       // rows beyond the last existing one re-read it (outputs unused)
   const int nk = X3 ? p.K / 32 : p.K / P::BK;              // K-tiles of 128 operand bytes per row
 
   // one staging quarter = 16 pieces of 1 KB (8 rows of 128 B); this wave moves pieces 2 wave and 2 wave + 1
@@ -639,7 +690,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_pp(GemmParams p) {
       const int row0 = is_a ? a_quarter_row(q, quarter == 3) : w_quarter_row(q, quarter == 2);
       const int row = row0 + lane / 8;
       const int chunk = (lane % 8) ^ P::swz(row);
-      const char* g = (is_a ? p.a_hi + (int64_t)(m0 + row) * ld : p.w_hi + (int64_t)(n0 + row) * ld) + kbyte + chunk * 16;
+      const char* g = (is_a ? p.a_hi + (int64_t)min(m0 + row, a_last) * lda : p.w_hi + (int64_t)(n0 + row) * ldw) + kbyte + chunk * 16;
       glds16(g, sbase + (is_a ? 0 : P::kWOff) + row0 * P::kRowBytes);
     }
   };
@@ -817,7 +868,7 @@ template <int TERMS, int EPI, int FP16>
 static hipError_t launch_one(const GemmParams& p, hipStream_t s) {
   const int ntiles = (p.M / BM) * (p.N / BN);
   // interleaved split operands (fc_0's X and packed weight in the bf16 formats): always the ping-pong schedule
-  if constexpr (FP16 == 0 && (EPI == EPI_RELU_SPLIT || EPI == EPI_F32)) {
+  if constexpr (FP16 == 0 && (EPI == EPI_RELU_SPLIT || EPI == EPI_F32 || EPI == EPI_DX)) {
     if (p.x3i) {
       if constexpr (TERMS == 3) hipLaunchKernelGGL((k_gemm_nt_pp<EPI, 0, true, 3>), dim3(ntiles), dim3(512), 0, s, p);
       else hipLaunchKernelGGL((k_gemm_nt_pp<EPI, 0, true, 1>), dim3(ntiles), dim3(512), 0, s, p);
@@ -825,6 +876,8 @@ static hipError_t launch_one(const GemmParams& p, hipStream_t s) {
     }
   }
   if (p.x3i) return hipErrorInvalidValue;
+  // operand strides, a row limit or a row vector exist in the ping-pong kernel only
+  const bool need_pp = p.lda || p.ldw || p.a_rows || p.rowvec;
   // MFMA shape per epilogue (measured, fp16, P = 160k): 32x32x16 has the cheaper 64-B store runs on the short-K
   // layers (fc_1 0.074 vs 0.086 ms), 16x16x32 the cheaper row reduction of the fused fc_2 + fc_out epilogue (0.045
   // vs 0.058 ms) and, on the long-K ping-pong schedule, the higher clock (fc_0 0.55 -> 0.49 ms)
@@ -840,7 +893,7 @@ static hipError_t launch_one(const GemmParams& p, hipStream_t s) {
 #define LIST_PP_MIN_K 512
 #endif
     if constexpr (TERMS == 1 && (EPI == EPI_RELU_SPLIT || EPI == EPI_F32 || (kPpShape16 && (EPI == EPI_DX || EPI == EPI_MASK_SPLIT)))) {
-      if (p.K >= LIST_PP_MIN_K) {
+      if (p.K >= LIST_PP_MIN_K || need_pp) {
         if (!p.plain_loop) hipLaunchKernelGGL((k_gemm_nt_pp<EPI, FP16, kPpShape16>), dim3(ntiles), dim3(512), 0, s, p);
         else if (kPpShape16) hipLaunchKernelGGL((k_gemm_nt16<TERMS, EPI, FP16>), dim3(ntiles), dim3(512), 0, s, p);
         else hipLaunchKernelGGL((k_gemm_nt<TERMS, EPI, FP16>), dim3(ntiles), dim3(512), 0, s, p);
@@ -848,6 +901,7 @@ static hipError_t launch_one(const GemmParams& p, hipStream_t s) {
       }
     }
 #endif
+    if (need_pp) return hipErrorInvalidValue;
 #ifndef LIST_X3_SHAPE32      // the hi/lo-split long-K product (fc_0 in bf16x3) on the 16x16x32 shape: 1.52 -> 1.43 ms
     if constexpr (TERMS == 3 && (EPI == EPI_RELU_SPLIT || EPI == EPI_F32)) {
       if (p.K >= 1024) {

@@ -87,6 +87,17 @@ int check_query_common(const ListQueryArgs* a, FeatLayout* L) {
     if ((int64_t)a->map_size * a->map_size * a->img_C >= (int64_t)1 << 31)
       return fail(LIST_ERR_SHAPE, "image map larger than 2^31 elements");
   }
+  if (a->percep_proj) {
+    // the projected sample (H1 floats) lives in the perceptual block of the point's X row; fc_0 starts behind it
+    if (a->percep_feat) return fail(LIST_ERR_ARG, "percep_proj and percep_feat exclude each other");
+    const int xbytes = a->precision == LIST_PREC_FP16 ? 2 : 4;            // per column of X (hi + lo in the split formats)
+    if (!aligned16(a->percep_proj) || a->img_C % 64 || a->H1 % 8 || (int64_t)a->H1 * 4 > (int64_t)a->img_C * xbytes)
+      return fail(LIST_ERR_UNSUPPORTED, "percep_proj needs img_C %% 64 == 0, H1 %% 8 == 0 and H1 * 4 <= img_C * %d bytes", xbytes);
+    if ((int64_t)a->map_size * a->map_size * a->H1 >= (int64_t)1 << 31)
+      return fail(LIST_ERR_SHAPE, "projected map larger than 2^31 elements");
+    if ((a->precision == LIST_PREC_FP16) != (a->img_dtype == LIST_MAP_F16))
+      return fail(LIST_ERR_UNSUPPORTED, "percep_proj: fp16 operands pair with fp16 maps, the bf16 formats with fp32 maps");
+  }
   return LIST_OK;
 }
 
@@ -279,6 +290,70 @@ int64_t list_query_chunk_rows(size_t workspace_bytes, int64_t n_points, int32_t 
   return chunk_rows_for(workspace_bytes, n_points, (F + kKTile - 1) / kKTile * kKTile, H1, H2);
 }
 
+// ------------------------------------------------------------------------------------------ projected perceptual map
+static int64_t proj_rows(int32_t B, int32_t map_size) {
+  const int64_t px = (int64_t)B * map_size * map_size;
+  return (px + kRowTile - 1) / kRowTile * kRowTile;
+}
+
+size_t list_percep_proj_bytes(int32_t B, int32_t map_size, int32_t H1, int32_t precision) {
+  if (B <= 0 || map_size < 2 || H1 <= 0) return 0;
+  return (size_t)proj_rows(B, map_size) * H1 * (precision == LIST_PREC_FP16 ? 2 : 4);
+}
+
+size_t list_percep_proj_scratch_bytes(int32_t B, int32_t map_size, int32_t img_C, int32_t precision) {
+  if (B <= 0 || map_size < 2 || img_C <= 0) return 0;
+  if (precision == LIST_PREC_FP16) return 0;
+  return (size_t)B * map_size * map_size * img_C * 4;          // bf16 hi + lo halfs of the fp32 map, interleaved
+}
+
+int list_prep_percep_proj(const void* img_map, int32_t img_dtype, int32_t B, int32_t map_size,
+                          const int32_t vox_C[LIST_N_VOX_LEVELS], int32_t img_C, const void* packed_mlp,
+                          int32_t H1, int32_t H2, int32_t H3, int32_t precision, void* proj,
+                          size_t proj_bytes, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!img_map || !vox_C || !packed_mlp || !proj) return fail(LIST_ERR_ARG, "NULL pointer");
+  if (precision < LIST_PREC_BF16X3 || precision > LIST_PREC_FP16) return fail(LIST_ERR_ARG, "precision=%d", precision);
+  if (B <= 0 || map_size < 2) return fail(LIST_ERR_SHAPE, "B=%d map_size=%d", B, map_size);
+  FeatLayout L;
+  if (!make_layout(vox_C, img_C, &L)) return fail(LIST_ERR_UNSUPPORTED, "unsupported channel counts");
+  const bool fp16 = precision == LIST_PREC_FP16;
+  if (img_C % 64 || H1 % 256 || H1 <= 0)
+    return fail(LIST_ERR_UNSUPPORTED, "percep_proj needs img_C %% 64 == 0 and H1 %% 256 == 0 (img_C=%d, H1=%d)", img_C, H1);
+  if (fp16 != (img_dtype == LIST_MAP_F16))
+    return fail(LIST_ERR_UNSUPPORTED, "percep_proj: fp16 operands pair with fp16 maps, the bf16 formats with fp32 maps");
+  if (!aligned16(img_map) || !aligned16(packed_mlp) || !aligned16(proj) || (scratch && !aligned16(scratch)))
+    return fail(LIST_ERR_SHAPE, "buffers must be 16-byte aligned");
+  if (proj_bytes < list_percep_proj_bytes(B, map_size, H1, precision))
+    return fail(LIST_ERR_WORKSPACE, "proj buffer too small: %zu < %zu", proj_bytes, list_percep_proj_bytes(B, map_size, H1, precision));
+  const size_t need = list_percep_proj_scratch_bytes(B, map_size, img_C, precision);
+  if (need && (!scratch || scratch_bytes < need))
+    return fail(LIST_ERR_WORKSPACE, "scratch too small: %zu < %zu", scratch_bytes, need);
+  const PackedMlp pk = packed_mlp_layout(L.Kp, H1, H2, H3);
+  if (!fp16 && pk.w0_lo != pk.w0_hi + (size_t)H1 * L.Kp * 2)
+    return fail(LIST_ERR_ARG, "internal: hi / lo planes of the packed fc_0 weight are not contiguous");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t px = (int64_t)B * map_size * map_size;
+  const char* a_ptr = (const char*)img_map;
+  if (!fp16) {
+    hipError_t e = launch_split_xi((const float*)img_map, (unsigned short*)scratch, px * img_C, s);
+    if (e != hipSuccess) return hip_fail(e, "map split launch");
+    a_ptr = (const char*)scratch;
+  }
+  // proj[pixel][n] = sum_c map[pixel][c] * W0[n][c]: the perceptual block is the FIRST img_C columns of the packed weight
+  GemmParams gp;
+  memset(&gp, 0, sizeof(gp));
+  gp.fmt = fp16 ? FMT_FP16 : FMT_BF16_SPLIT;
+  gp.x3i = fp16 ? 0 : 1;
+  gp.a_hi = a_ptr; gp.a_lo = a_ptr;
+  gp.w_hi = (const char*)packed_mlp + pk.w0_hi; gp.w_lo = gp.w_hi;
+  gp.M = (int)proj_rows(B, map_size); gp.N = H1; gp.K = img_C;
+  gp.lda = img_C; gp.ldw = L.Kp; gp.a_rows = (int)px;
+  gp.dx = proj; gp.dx_f16 = fp16 ? 1 : 0; gp.n_store = H1; gp.ldo = H1;
+  hipError_t e = launch_gemm(gp, precision == LIST_PREC_BF16X3 ? 3 : 1, EPI_DX, s);
+  if (e != hipSuccess) return hip_fail(e, "projection launch");
+  return LIST_OK;
+}
+
 int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
   FeatLayout L;
   if (a && a->B >= 0 && a->N >= 0 && (int64_t)a->B * a->N == 0) return LIST_OK;   // empty query: nothing to do
@@ -350,6 +425,14 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
     gp.x3i = g.fmt == FMT_FP16 ? 0 : 1;
     if (gp.x3i && (ws.x_lo != ws.x_hi + (size_t)rows * L.Kp * 2 || pk.w0_lo != pk.w0_hi + (size_t)a->H1 * L.Kp * 2))
       return fail(LIST_ERR_ARG, "internal: hi / lo planes of X or of the packed fc_0 weight are not contiguous");
+    if (a->percep_proj) {
+      // the perceptual block (the first img_C columns) is left out of the K loop; its contribution was sampled from
+      // the projected map into the head of every X row and is added in the epilogue
+      const int64_t skip = (int64_t)a->img_C * (gp.x3i ? 4 : 2);
+      gp.a_hi += skip; gp.w_hi += skip;
+      gp.K = L.Kp - a->img_C; gp.lda = L.Kp; gp.ldw = L.Kp;
+      gp.rowvec = wsb + ws.x_hi; gp.rowvec_stride = (int64_t)L.Kp * (gp.x3i ? 4 : 2);
+    }
     gp.out_hi = (unsigned short*)(wsb + ws.h1_hi);
     gp.out_lo = terms == 3 ? (unsigned short*)(wsb + ws.h1_lo) : nullptr;
     gp.ldo = a->H1;
@@ -366,6 +449,7 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
     e = launch_gemm(gp, terms, EPI_RELU_SPLIT, s);
     if (e != hipSuccess) return hip_fail(e, "gated fc_0 launch");
     gp.tile_gate = nullptr; gp.x3i = 0;
+    gp.lda = gp.ldw = 0; gp.rowvec = nullptr;
     mark(LIST_STAGE_EXACT);
     // fc_1 + ReLU
     gp.a_hi = wsb + ws.h1_hi; gp.a_lo = wsb + ws.h1_lo;
@@ -398,6 +482,7 @@ int list_gather_features_fwd(const ListQueryArgs* a, float* out, void* stream) {
   int rc = check_query_common(a, &L);
   if (rc != LIST_OK) return rc;
   if (!out) return fail(LIST_ERR_ARG, "out is NULL");
+  if (a->percep_proj) return fail(LIST_ERR_UNSUPPORTED, "percep_proj leaves the perceptual features out of X");
   const int64_t P = (int64_t)a->B * a->N;
   const int H1 = a->H1 > 0 ? a->H1 : 512, H2 = a->H2 > 0 ? a->H2 : 256;
   const int64_t rows = chunk_rows_for(a->workspace_bytes, P, L.Kp, H1, H2);
@@ -497,6 +582,7 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   if (a->precision < LIST_PREC_BF16X3 || a->precision > LIST_PREC_FP16)
     return fail(LIST_ERR_ARG, "precision=%d", a->precision);
   if (ga->vox_adjoint < 0 || ga->vox_adjoint > 2) return fail(LIST_ERR_ARG, "vox_adjoint=%d", ga->vox_adjoint);
+  if (a->percep_proj) return fail(LIST_ERR_UNSUPPORTED, "a forward with percep_proj (inference) keeps no perceptual features for the backward");
   const int64_t P = (int64_t)a->B * a->N;
   if (P > kMaxChunkRows)
     return fail(LIST_ERR_UNSUPPORTED, "backward handles up to %lld points per call (got %lld)",

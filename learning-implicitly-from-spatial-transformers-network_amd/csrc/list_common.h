@@ -356,6 +356,10 @@ struct GemmParams {
   int* nan_tiles;                                            // EPI_RELU_SPLIT: nan_tiles[m0 / 256] = 1 if the tile's output holds a NaN
   const int* tile_gate;                                      // run only the row tiles with tile_gate[m0 / 256] != 0
   int x3i;                                                   // split formats: a_hi / w_hi hold hi and lo interleaved (xi_off); a_lo / w_lo unused
+  // ping-pong kernel only (fc_0 without its perceptual block; the projection of the perceptual map):
+  int lda, ldw;                                              // row strides of A / W in elements (0: K)
+  int a_rows;                                                // rows of A that exist (0: M); staging re-reads the last one beyond
+  const char* rowvec; int64_t rowvec_stride;                 // EPI_RELU_SPLIT: fp32 [M][N] row vectors added before the ReLU (byte stride), or null
 };
 
 // EPI_MASK_SPLIT: out = acc where the saved activation is positive (ReLU backward), no bias;
@@ -383,6 +387,7 @@ hipError_t launch_transpose_vox_fused(const ListMap3D* maps, void* const* outs, 
                                       hipStream_t s);
 hipError_t launch_prep_weights(const ListMlpWeights& w, const FeatLayout& L, const PackedMlp& P,
                                char* packed, hipStream_t s);
+hipError_t launch_split_xi(const float* x, unsigned short* out, int64_t n, hipStream_t s);
 hipError_t launch_split(const float* x, unsigned short* hi, unsigned short* lo, int64_t n, int fmt,
                         hipStream_t s);
 struct SortBuffers { int* order; int* order_img; int* row_of; int* keys; int* keys2; int* bins; };

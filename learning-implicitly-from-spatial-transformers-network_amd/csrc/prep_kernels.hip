@@ -685,6 +685,28 @@ __global__ __launch_bounds__(256) void k_split(const float4* __restrict__ x, uin
   }
 }
 
+// fp32 [rows][C] (C % 32 == 0) -> bf16 hi / lo halfs interleaved in 64-B blocks (xi_off): the A operand of the
+// perceptual-map projection in the split formats
+__global__ __launch_bounds__(256) void k_split_xi(const float4* __restrict__ x, unsigned short* __restrict__ out,
+                                                  int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    uint2 h, l;
+    split4(x[i], h, l);
+    unsigned short* d = out + xi_off(4 * i);
+    *(uint2*)d = h;
+    *(uint2*)(d + kXiLo) = l;
+  }
+}
+
+hipError_t launch_split_xi(const float* x, unsigned short* out, int64_t n, hipStream_t s) {
+  const int64_t n4 = n / 4;
+  int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_split_xi, dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)x, out, n4);
+  return hipGetLastError();
+}
+
 hipError_t launch_split(const float* x, unsigned short* hi, unsigned short* lo, int64_t n, int fmt,
                         hipStream_t s) {
   const int64_t n4 = n / 4;

@@ -71,7 +71,7 @@ class ListQueryArgs(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("precision", C.c_int32),
                 ("stage_events", C.POINTER(C.c_void_p)), ("no_sort", C.c_int32),
-                ("stage_event_sets", C.c_int32)]
+                ("stage_event_sets", C.c_int32), ("percep_proj", C.c_void_p)]
 
 
 class ListMlpGrads(C.Structure):
@@ -124,6 +124,11 @@ EXPORTS = {
     "list_vox_pack_bytes": (C.c_size_t, [C.POINTER(ListMap3D), C.c_int32, C.c_int32]),
     "list_prep_vox_maps": (C.c_int, [C.POINTER(ListMap3D), C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
                                      C.POINTER(ListVoxLevel), C.c_void_p]),
+    "list_percep_proj_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "list_percep_proj_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "list_prep_percep_proj": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32,
+                                        C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                        C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     "list_packed_mlp_bytes": (C.c_size_t, [C.POINTER(ListMlpWeights)]),
     "list_prep_mlp_weights": (C.c_int, [C.POINTER(ListMlpWeights), C.c_void_p, C.c_size_t,
                                         C.c_void_p]),
@@ -326,6 +331,35 @@ def prep_mlp_weights_bwd(params, vox_C, img_C=1024, precision="bf16x3"):
     return packed
 
 
+class PercepProj:
+    """The perceptual map projected through the perceptual block of fc_0 (list_prep_percep_proj): valid for the
+    prepared map and the packed weights it was made from."""
+
+    def __init__(self, data, img, packed):
+        self.data, self.img, self.packed = data, img, packed
+
+
+def prep_percep_proj(img, packed, precision="bf16x3"):
+    """Inference with many points per image (a marching-cubes grid): fc_0 is linear, so its perceptual block applied
+    to a bilinear sample of the prepared map equals the bilinear sample of the projected map.  -> PercepProj for
+    sdf_query(..., percep_proj=...).  Raises RuntimeError(unsupported) for shapes / dtype pairs the path does not take."""
+    lib = load()
+    prec = PRECISIONS[precision] if isinstance(precision, str) else int(precision)
+    B = img.data.shape[0]
+    nbytes = lib.list_percep_proj_bytes(B, img.map_size, packed.H1, prec)
+    sbytes = lib.list_percep_proj_scratch_bytes(B, img.map_size, img.channels, prec)
+    dev = img.data.device
+    out = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    scratch = torch.empty((max(sbytes, 16),), dtype=torch.uint8, device=dev)
+    vc = (C.c_int32 * N_VOX_LEVELS)(*[int(c) for c in packed.vox_C])
+    with torch.cuda.device(dev):
+        _check(lib.list_prep_percep_proj(img.data.data_ptr(), img.dtype, B, img.map_size, vc, img.channels,
+                                         packed.data.data_ptr(), packed.H1, packed.H2, packed.H3, prec,
+                                         out.data_ptr(), nbytes, scratch.data_ptr() if sbytes else None, sbytes,
+                                         _stream()), "list_prep_percep_proj")
+    return PercepProj(out, img, packed)       # (the scratch is released stream-ordered by the caching allocator)
+
+
 # Scratch of the forward (X, H1, H2, point orders: 1.2 - 4.6 GB).  It lives in THREAD-LOCAL storage, keyed by
 # (device, stream): two threads, or two streams of one thread, never share one (the kernels of a call keep using
 # it after the call has returned), and it cannot outlive its thread -- nn.DataParallel starts fresh threads for
@@ -420,7 +454,7 @@ class QueryContext:
 
 def sdf_query(query, trans_mat, img, vox, packed, perm=(2, 1, 0), scale=2.0, precision="bf16x3",
               percep_feat=None, out=None, stage_events=None, sort_points=True, clamp_hi=136.0,
-              save_for_backward=False):
+              save_for_backward=False, percep_proj=None):
     """The fused hot path, network/models.py:91-97 -> sdf [B,N] (float32).
 
     stage_events: optional ctypes array (c_void_p * (n * N_STAGES)) of hipEvent_t handles, one set of N_STAGES
@@ -434,6 +468,13 @@ def sdf_query(query, trans_mat, img, vox, packed, perm=(2, 1, 0), scale=2.0, pre
     a, keep = _fill_query_args(query, perm, scale, vox, packed, precision, trans_mat, img, percep_feat,
                                clamp_hi, private_workspace=save_for_backward)
     a.no_sort = 0 if sort_points else 1
+    if percep_proj is not None:
+        if save_for_backward or percep_feat is not None:
+            raise RuntimeError("percep_proj is an inference path: no backward, no pre-pooled features")
+        if percep_proj.img is not img or percep_proj.packed is not packed:
+            raise RuntimeError("percep_proj was made from another prepared map or other packed weights")
+        a.percep_proj = percep_proj.data.data_ptr()
+        keep.append(percep_proj)
     if stage_events is not None:
         a.stage_events = C.cast(stage_events, C.POINTER(C.c_void_p))
         a.stage_event_sets = max(1, len(stage_events) // N_STAGES)

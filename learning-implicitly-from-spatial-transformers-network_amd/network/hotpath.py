@@ -219,10 +219,23 @@ def sdf_query(query, trans_mat, img_maps, vox_maps, mlp_params, *, perm=(2, 1, 0
             mlp, lambda: hip.prep_mlp_weights(mlp_dict, vox.channels, img_C, precision))
 
     def run():
+        proj = None
+        # many points per image on fixed maps and weights (an inference grid): the perceptual block of fc_0 is applied
+        # to the 137^2 map once (hip.prep_percep_proj, cached with the map and the weights) instead of per point
+        if (ordered_points and img is not None and not training and not torch.is_grad_enabled()
+                and query.shape[1] >= 4 * img.map_size * img.map_size):
+            def make():
+                try:
+                    return hip.prep_percep_proj(img, packed, precision)
+                except RuntimeError as e:          # shapes / dtype pairs the projection does not take
+                    if "failed (-5)" in str(e):          # LIST_ERR_UNSUPPORTED
+                        return False
+                    raise
+            proj = caches.setdefault("proj:" + str(precision), _Cache()).get([img.data, packed.data], make) or None
         return hip.sdf_query(query.detach(), trans_mat.detach() if trans_mat is not None else None,
                              img, vox, packed, perm=perm, scale=scale, precision=precision,
                              percep_feat=percep_feat.detach() if percep_feat is not None else None,
-                             sort_points=not ordered_points)
+                             sort_points=not ordered_points, percep_proj=proj)
 
     diff = [t for t in (trans_mat, percep_feat, *img_maps, *vox_maps, *mlp)
             if t is not None and t.requires_grad]

@@ -191,6 +191,36 @@ def test_gradients_flow_through_the_query(net):
     net.cpu()
 
 
+def test_executor_grid_prediction_on_the_projected_perceptual_map(cfg, net):
+    """A grid with at least 4 x 137^2 points per image: predict_grid's queries take the projected perceptual map
+    (fc_0's perceptual block applied to the map once per image, hip.prep_percep_proj) -- the same field as the
+    standard per-point path up to rounding, in both operand formats."""
+    net.to(DEV)
+    from list_amd.train import _Module
+    img = torch.from_numpy(synth.uniform(78, (1, 3, 64, 64))).to(DEV)
+    with torch.no_grad():
+        enc = net.encode(img)
+    net.encode = lambda *a, **k: enc   # freeze the per-image stage so only the query path is compared
+    prec0 = net.sdf_decoder.precision
+    try:
+        for prec, tol in (("bf16x3", 5e-6), ("fp16", 1e-4)):
+            net.sdf_decoder.precision = prec
+            cfg2 = arguments.default_config(vox_res=32, train_batch_size=2, mcube_znum=44, test_pointnum=5000)
+            cfg2.device = torch.device(DEV)
+            ex = utils.get_class("network.executors.LIST")(cfg2, _Module(net))
+            vol, _, _ = ex.predict_grid(img)
+            assert vol.shape == (44, 44, 44) and torch.isfinite(vol).all()
+            assert "proj:" + prec in net.sdf_decoder._caches[("device", torch.device(DEV).index or 0)]
+            grid = torch.tensor(utils.create_grid_points_from_bounds(-0.5, 0.5, 44)).float().unsqueeze(0).to(DEV)
+            with torch.no_grad():
+                one = net.query_sdf(grid, enc[0], enc[1], enc[2])          # standard path (sorted points, no projection)
+            assert float((one.view(44, 44, 44) / cfg2.sdf_scale - vol).abs().max()) < tol
+    finally:
+        net.sdf_decoder.precision = prec0
+        del net.encode
+    net.cpu()
+
+
 def test_executor_grid_prediction(cfg, net):
     """Inference driver (reference executors.py:191-231): chunked device-side grid == one-shot query."""
     net.to(DEV)

@@ -36,9 +36,9 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_error_string_without_gpu():
     from list_amd import hip
     lib = hip.load()
-    assert lib.list_abi_version() == 4
+    assert lib.list_abi_version() == 5
     text = open(os.path.join(ROOT, "include", "list_hip.h")).read()
-    assert "#define LIST_ABI_VERSION 4" in text
+    assert "#define LIST_ABI_VERSION 5" in text
     # argument validation happens before any HIP call: a NULL args struct is rejected cleanly
     assert lib.list_sdf_query_fwd(None, None) == -1
     assert b"NULL" in lib.list_last_error()
@@ -49,6 +49,11 @@ def test_abi_version_and_error_string_without_gpu():
     big = lib.list_query_workspace_bytes(256 ** 3, 3610, 512, 256, 256)
     assert lib.list_query_chunk_rows(big, 256 ** 3, 3610, 512, 256, 256) == 262144
     assert lib.list_query_chunk_rows(1 << 20, 256 ** 3, 3610, 512, 256, 256) == 0
+    # projected perceptual map (ABI 5): 18769 pixels pad to 74 row tiles; fp16 halfs / fp32 floats; fp16 needs no scratch
+    assert lib.list_percep_proj_bytes(1, 137, 512, 2) == 18944 * 512 * 2
+    assert lib.list_percep_proj_bytes(1, 137, 512, 0) == 18944 * 512 * 4
+    assert lib.list_percep_proj_scratch_bytes(1, 137, 1024, 2) == 0
+    assert lib.list_percep_proj_scratch_bytes(1, 137, 1024, 0) == 18769 * 1024 * 4
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -112,6 +112,30 @@ def test_interleaved_split_operands_are_bit_identical_to_the_planes(hip):
                 assert torch.equal(x, y), (rep, M, N, K, prec)
 
 
+@pytest.mark.parametrize("precision,tol_std,tol_ref", [("bf16x3", 3e-6, 1e-4), ("fp16", 8e-5, 1e-4)])
+def test_projected_perceptual_map_matches_the_standard_path(hip, golden_dir, precision, tol_std, tol_ref):
+    """Inference path (list_prep_percep_proj): fc_0's perceptual block applied to the 137^2 map once and sampled per
+    point, fc_0 itself skipping that block -- linearity, so the SDF equals the standard path's up to rounding, and the
+    reference's within the path's bound; sorted and caller-ordered points, chunked calls included."""
+    for name in ("small", "real"):
+        c = cases.build_case(name)
+        g = golden(golden_dir, name)
+        img, vox, packed = prepare(hip, c, precision)
+        q, T = dev(c["query"]), dev(c["trans_mat"])
+        std = hip.sdf_query(q, T, img, vox, packed, precision=precision)
+        proj = hip.prep_percep_proj(img, packed, precision)
+        for sort in (True, False):
+            got = hip.sdf_query(q, T, img, vox, packed, precision=precision, percep_proj=proj, sort_points=sort)
+            assert float((got - std).abs().max()) < tol_std, (name, sort, float((got - std).abs().max()))
+            assert np.abs(got.cpu().numpy() - g["sdf"]).max() < tol_ref
+        # another prepared map or other weights are refused
+        img2, _, packed2 = prepare(hip, c, precision)
+        with pytest.raises(RuntimeError):
+            hip.sdf_query(q, T, img2, vox, packed, precision=precision, percep_proj=proj)
+        with pytest.raises(RuntimeError):
+            hip.sdf_query(q, T, img, vox, packed, precision=precision, percep_proj=proj, save_for_backward=True)
+
+
 def test_gemm_kernel_identity_asymmetric(hip):
     """A = I against an asymmetric W catches a transposed C-write or a wrong k-order."""
     K = N = 256
