@@ -31,6 +31,8 @@ def kernel_trace(d):
             # exits at its first instruction on finite inputs: listed on its own line
             if k.startswith("k_gemm_nt") and dur < 15000:
                 k += " [gated exit]"
+            elif k.startswith("k_gemm"):          # one template serves several layers: tell them apart by their grid
+                k += f" grid {r.get('Grid_Size_X', r.get('Grid_Size', ''))}"
             rows[k].append((dur, r))
     return rows
 
@@ -41,6 +43,8 @@ def counters(d):
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
             if k:
+                if k.startswith("k_gemm"):
+                    k += f" grid {r.get('Grid_Size_X', r.get('Grid_Size', ''))}"
                 acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return acc
 
@@ -51,12 +55,12 @@ def main():
         kt = kernel_trace(d)
         if kt:
             out.append(f"== kernel trace: {d}")
-            out.append(f"{'kernel':34s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} "
+            out.append(f"{'kernel':46s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} "
                        f"{'total_ms':>10s} {'vgpr':>5s} {'lds':>7s} {'grid':>9s} {'wg':>5s}")
             for k, v in sorted(kt.items(), key=lambda kv: -sum(t for t, _ in kv[1])):
                 ts = [t for t, _ in v]
                 r = v[-1][1]
-                out.append(f"{k:34s} {len(ts):6d} {sum(ts)/len(ts)/1e3:10.1f} {min(ts)/1e3:10.1f} "
+                out.append(f"{k:46s} {len(ts):6d} {sum(ts)/len(ts)/1e3:10.1f} {min(ts)/1e3:10.1f} "
                            f"{max(ts)/1e3:10.1f} {sum(ts)/1e6:10.3f} {r.get('VGPR_Count',''):>5s} "
                            f"{r.get('LDS_Block_Size',''):>7s} {r.get('Grid_Size_X', r.get('Grid_Size','')):>9s} "
                            f"{r.get('Workgroup_Size_X', r.get('Workgroup_Size','')):>5s}")
@@ -65,7 +69,7 @@ def main():
             out.append(f"== counters: {d}  (per-dispatch mean; FETCH_SIZE/WRITE_SIZE in KB as reported)")
             for k, c in sorted(cs.items()):
                 for name, vals in sorted(c.items()):
-                    out.append(f"{k:34s} {name:14s} n={len(vals):4d} mean={sum(vals)/len(vals):14.1f} "
+                    out.append(f"{k:46s} {name:14s} n={len(vals):4d} mean={sum(vals)/len(vals):14.1f} "
                                f"max={max(vals):14.1f}")
     print("\n".join(out))
 
