@@ -124,11 +124,16 @@ class LIST:
         # and a 65 536-point call is dominated by its ~20 launches and the Python dispatch: calls of at least 2^20
         # points (256^3 grid: 111.6 -> 142 M points/s in fp16, 69 -> 78 M in bf16x3)
         step = max(int(self.test_pointnum), 1 << 20)
+        # one decision for the whole grid (every call and every rank of a sharded grid then computes the same bits): with
+        # at least 4 x 137^2 points on the image, fc_0's perceptual block is applied to the map once (hotpath.sdf_query)
+        ms = net.percep_pooling.map_size
+        project = total >= 4 * ms * ms
         for s in range(begin, end, step):
             e = min(s + step, end)
             pts = utils.grid_points_on_device(-0.5, 0.5, res, dev, s, e).unsqueeze(0)
             # (raster order: consecutive grid points are neighbours already, the forward skips its point sort)
-            out[s - begin:e - begin] = net.query_sdf(pts, feat_l2, vox_feat, transmat, ordered_points=True)[0]
+            out[s - begin:e - begin] = net.query_sdf(pts, feat_l2, vox_feat, transmat, ordered_points=True,
+                                                     project_percep=project)[0]
         if world > 1:
             out = parallel.gather_ragged_points(out, total)
         return (out / self.sdf_scale).view(res, res, res), occ, vox_feat

@@ -187,11 +187,15 @@ def percep_pool(img_maps, pc, trans_mat, img):
 
 
 def sdf_query(query, trans_mat, img_maps, vox_maps, mlp_params, *, perm=(2, 1, 0), scale=2.0,
-              map_size=137, precision="bf16x3", percep_feat=None, caches=None, ordered_points=False):
+              map_size=137, precision="bf16x3", percep_feat=None, caches=None, ordered_points=False,
+              project_percep=None):
     """sdf [B,N] for raw queries; mlp_params: dict with the reference's fc_* keys.
     ordered_points: the queries already come in a spatially coherent order (a raster grid): the forward skips its
     Morton / pixel counting sort (same values; on a 256^3 inference grid the sort is 6 % of the query time and the
-    gathers run as fast without it).  Inference only."""
+    gathers run as fast without it).  Inference only.
+    project_percep: take the projected perceptual map (hip.prep_percep_proj) -- None: when ordered_points and the call
+    carries at least 4 map_size^2 points per image; a driver that cuts one grid into several calls passes True / False for
+    all of them so that every call (and every rank of a sharded grid) computes the same bits."""
     require_hip(query, "query")
     # nn.DataParallel replicas share the module's cache dict (replicate() copies attributes by reference) and run
     # in one thread per device: every device gets its own slots
@@ -222,8 +226,9 @@ def sdf_query(query, trans_mat, img_maps, vox_maps, mlp_params, *, perm=(2, 1, 0
         proj = None
         # many points per image on fixed maps and weights (an inference grid): the perceptual block of fc_0 is applied
         # to the 137^2 map once (hip.prep_percep_proj, cached with the map and the weights) instead of per point
-        if (ordered_points and img is not None and not training and not torch.is_grad_enabled()
-                and query.shape[1] >= 4 * img.map_size * img.map_size):
+        want = project_percep if project_percep is not None else (
+            ordered_points and img is not None and query.shape[1] >= 4 * img.map_size * img.map_size)
+        if want and img is not None and not training and not torch.is_grad_enabled():
             def make():
                 try:
                     return hip.prep_percep_proj(img, packed, precision)

@@ -78,9 +78,10 @@ class LIST(nn.Module):
         return feat_l2, vox_feat, trans_mat, pc, occ
 
     # ---- per-point stage: the HIP hot path ------------------------------------------------------------
-    def query_sdf(self, query, feat_l2, vox_feat, trans_mat, ordered_points=False):
+    def query_sdf(self, query, feat_l2, vox_feat, trans_mat, ordered_points=False, project_percep=None):
         return self.sdf_decoder.query(query, feat_l2, trans_mat, vox_feat,
-                                      map_size=self.percep_pooling.map_size, ordered_points=ordered_points)
+                                      map_size=self.percep_pooling.map_size, ordered_points=ordered_points,
+                                      project_percep=project_percep)
 
     def forward(self, img, query, trans_mat=None):
         feat_l2, vox_feat, trans_mat, _, _ = self.encode(img, trans_mat)

@@ -91,12 +91,12 @@ class VoxelDecoder2(VoxelDecoder):
                                  precision=self.precision, percep_feat=percep_feat, caches=self._caches)
 
     def query(self, query, img_featuremaps, trans_mat, feat, map_size=137, perm=(2, 1, 0), scale=2.0,
-              ordered_points=False):
+              ordered_points=False, project_percep=None):
         """Fused PerceptualPooling + VoxelDecoder2 on RAW queries (reference models.py:91-97) without
         materialising the [B,1024,N] perceptual tensor.  ordered_points: see hotpath.sdf_query."""
         return hotpath.sdf_query(query, trans_mat, img_featuremaps, feat, self.mlp_params(), perm=perm,
                                  scale=scale, map_size=map_size, precision=self.precision,
-                                 caches=self._caches, ordered_points=ordered_points)
+                                 caches=self._caches, ordered_points=ordered_points, project_percep=project_percep)
 
 
 # ======================================================================================= per-image modules
