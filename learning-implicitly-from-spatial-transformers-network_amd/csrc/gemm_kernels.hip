@@ -1,12 +1,15 @@
-// MFMA kernel of the implicit MLP (network/modules.py:276-281): out = act(A . W^T + bias) with
-// A [M][K] (points x features) and W [N][K] (Conv1d(k=1) weight) both bf16 hi/lo planes.
+// MFMA kernels of the implicit MLP (network/modules.py:276-281): out = act(A . W^T + bias) with
+// A [M][K] (points x features) and W [N][K] (Conv1d(k=1) weight) as bf16 hi/lo planes or one fp16 plane.
 //
-//   precision BF16X3: acc += A_hi.W_hi + A_hi.W_lo + A_lo.W_hi   (3 x v_mfma_f32_32x32x16_bf16,
-//                     fp32 accumulate; the dropped lo.lo term is ~2^-16 relative)
-//   precision BF16  : acc += A_hi.W_hi
+//   precision BF16X3: acc += A_lo.W_hi + A_hi.W_lo + A_hi.W_hi   (3 MFMAs per operand pair, fp32
+//                     accumulate; the dropped lo.lo term is ~2^-16 relative)
+//   precision BF16  : acc += A_hi.W_hi          precision FP16: acc += A.W (fp16 operands)
 //
+// Kernels: k_gemm_nt (plain 2-stage loop, 32x32x16 MFMA), k_gemm_nt16 (the same on 16x16x32), and
+// k_gemm_nt_pp (ping-pong schedule; from 8 K-tiles on; single-plane operands, or the split formats with their hi /
+// lo halfs interleaved in 64-B blocks -- fc_0's X and packed weight, the projection of the perceptual map).
 // Tiling (CDNA4, wave64): workgroup 256x256 outputs, 8 waves as 2(M) x 4(N), each wave 128x64 =
-// 4x2 tiles of 32x32 (128 accumulator registers).  Operand tiles go HBM/L2 -> LDS with
+// 4x2 tiles of 32x32 or 8x4 tiles of 16x16 (128 accumulator registers).  Operand tiles go HBM/L2 -> LDS with
 // global_load_lds_dwordx4 (no VGPR round trip), double-buffered 64-KB stages (128 KB LDS, one
 // workgroup per CU).  LDS rows are 64 B (BK = 32) or 128 B (BK = 64); the 16-B chunk index is XORed
 // with (row>>2)&3 resp. (row>>1)&7 -- on the SOURCE address for the linear LDS-DMA write and on the
