@@ -306,6 +306,15 @@ __global__ __launch_bounds__(LIST_PREP_THREADS) void k_prep_img_rows(PrepRowsArg
   const float wx1 = fx - (float)x0, wx0 = 1.f - wx1;
   const float* p0 = m.data + (int64_t)b * m.sb + (int64_t)c * m.sc + (int64_t)x0 * m.sw;
   const float* p1 = m.data + (int64_t)b * m.sb + (int64_t)c * m.sc + (int64_t)x1 * m.sw;
+#ifndef LIST_PREP_NO_PAIR
+  // NCHW-like source (x contiguous): taps x0, x1 = x0 + 1 (or x0 at the right edge) come from the pair (xb, xb + 1)
+  const bool pair = !vec && m.sw == 1 && m.W >= 2;
+#else
+  const bool pair = false;
+#endif
+  const int xb = min(x0, m.W - 2);
+  const bool sel0 = x0 != xb, sel1 = x1 != xb;
+  const float* pb = m.data + (int64_t)b * m.sb + (int64_t)c * m.sc + (int64_t)xb;
 
   // (Tried: fetching the source-row segment of the tile with loads that run along x and turning it through LDS
   // into [column][64 channels] -- 0.29 ms instead of 0.19: two barriers and an LDS round trip per fetch lengthen
@@ -321,6 +330,14 @@ __global__ __launch_bounds__(LIST_PREP_THREADS) void k_prep_img_rows(PrepRowsArg
       const float4 b0 = *(const float4*)r1, b1 = *(const float4*)(r1 + 4);
       u[0] = a0.x; u[1] = a0.y; u[2] = a0.z; u[3] = a0.w; u[4] = a1.x; u[5] = a1.y; u[6] = a1.z; u[7] = a1.w;
       v[0] = b0.x; v[1] = b0.y; v[2] = b0.z; v[3] = b0.w; v[4] = b1.x; v[5] = b1.y; v[6] = b1.z; v[7] = b1.w;
+    } else if (pair) {              // x-contiguous source: the two taps of a channel are one 8-byte load
+      const float* rb = pb + (int64_t)r * m.sh;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        typedef __attribute__((ext_vector_type(2))) float f2u __attribute__((aligned(4)));
+        const f2u a = *(const f2u*)(rb + (int64_t)k * m.sc);
+        u[k] = sel0 ? a.y : a.x; v[k] = sel1 ? a.y : a.x;
+      }
     } else {
 #pragma unroll
       for (int k = 0; k < 8; ++k) { u[k] = r0[(int64_t)k * m.sc]; v[k] = r1[(int64_t)k * m.sc]; }
