@@ -1117,8 +1117,12 @@ hipError_t launch_img_grad(const ScatterParams& sp, const FeatLayout& L, const L
 //   2. out[c][xs] = sum_ox wx(ox, xs) R[ox][c]          R through LDS, per-xs tap lists in CSR form;
 //   3. the [64][W] tile turns through LDS so the NCHW writes run along x.
 constexpr int kAdjMaxMs = 320;             // largest supported map_size
-constexpr int kAdjXl = 16;                 // x lanes of phase 1
-constexpr int kAdjCols = kAdjMaxMs / kAdjXl;
+#ifndef LIST_ADJ_CG
+#define LIST_ADJ_CG 32
+#endif
+constexpr int kAdjCg = LIST_ADJ_CG;        // channels per workgroup (A/B: 64 = 72 KB of LDS, two workgroups per CU)
+constexpr int kAdjXl = 256 / (kAdjCg / 4); // x lanes of phase 1 (a lane owns 4 channels)
+constexpr int kAdjCols = (kAdjMaxMs + kAdjXl - 1) / kAdjXl;
 
 // the forward's footprint of map index o on a source axis of S pixels
 __device__ __forceinline__ void adj_footprint(int o, int S, int ms, int& i0, int& i1, float& w0, float& w1) {
@@ -1145,21 +1149,21 @@ __global__ __launch_bounds__(256) void k_img_grad_level(const float* __restrict_
     if (i < lv.n && (int)blockIdx.x >= lv.wg_begin[i]) l = i;
   const ListMap2D m = lv.m[l];
   const int coff = lv.coff[l], maxper = lv.maxper[l];
-  const int cgroups = (m.C + 63) / 64;
+  const int cgroups = (m.C + kAdjCg - 1) / kAdjCg;
   const int widx = (int)blockIdx.x - lv.wg_begin[l];
   const int bx = widx / cgroups, by = widx - bx * cgroups;      // (image, source row) and 64-channel group
   extern __shared__ __attribute__((aligned(16))) float dyn[];
-  // dynamic LDS: R[ms][64] | tile[64][kAdjTileW + 1] | wy[ms] | wx[W][maxper] | ox_first[W] | ox_cnt[W]
+  // dynamic LDS: R[ms][kAdjCg] | tile[kAdjCg][kAdjTileW + 1] | wy[ms] | wx[W][maxper] | ox_first[W] | ox_cnt[W]
   float* R = dyn;
-  float* tile = R + ms * 64;
-  float* s_wy = tile + 64 * (kAdjTileW + 1);
+  float* tile = R + ms * kAdjCg;
+  float* s_wy = tile + kAdjCg * (kAdjTileW + 1);
   float* s_wx = s_wy + ms;
   int* ox_first = (int*)(s_wx + m.W * maxper);
   int* ox_cnt = ox_first + m.W;
   __shared__ int oy_range[2];
   const int ys = bx % m.H;
   const int b = bx / m.H;
-  const int c0 = by * 64;
+  const int c0 = by * kAdjCg;
   if (threadIdx.x == 0) { oy_range[0] = INT_MAX; oy_range[1] = INT_MIN; }
   __syncthreads();
   // map rows that touch source row ys: footprints are monotone, so they form one contiguous range
@@ -1191,8 +1195,8 @@ __global__ __launch_bounds__(256) void k_img_grad_level(const float* __restrict_
   }
   __syncthreads();
   // ---- phase 1
-  const int cq = threadIdx.x & 15, xl = threadIdx.x >> 4;
-  const int nc4 = min(64, m.C - c0) / 4;               // channel quads that exist (C % 4 == 0)
+  const int cq = threadIdx.x % (kAdjCg / 4), xl = threadIdx.x / (kAdjCg / 4);
+  const int nc4 = min(kAdjCg, m.C - c0) / 4;               // channel quads that exist (C % 4 == 0)
   float4 acc[kAdjCols];
 #pragma unroll
   for (int k = 0; k < kAdjCols; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1215,23 +1219,23 @@ __global__ __launch_bounds__(256) void k_img_grad_level(const float* __restrict_
 #pragma unroll
   for (int k = 0; k < kAdjCols; ++k) {
     const int ox = xl + kAdjXl * k;
-    if (ox < ms) *(float4*)(R + ox * 64 + cq * 4) = acc[k];
+    if (ox < ms) *(float4*)(R + ox * kAdjCg + cq * 4) = acc[k];
   }
   __syncthreads();
   // ---- phases 2 and 3, kAdjTileW source columns at a time
-  const int c = threadIdx.x & 63, xq = threadIdx.x >> 6;
+  const int c = threadIdx.x % kAdjCg, xq = threadIdx.x / kAdjCg;
   float* out = const_cast<float*>(m.data) + (int64_t)b * m.sb + (int64_t)ys * m.sh;
   for (int x0 = 0; x0 < m.W; x0 += kAdjTileW) {
     const int wt = min(kAdjTileW, m.W - x0);
-    for (int xs = xq; xs < wt; xs += 4) {
+    for (int xs = xq; xs < wt; xs += 256 / kAdjCg) {
       const int first = ox_first[x0 + xs], n = ox_cnt[x0 + xs];
       const float* wx = s_wx + (x0 + xs) * maxper;
       float a = 0.f;
-      for (int e = 0; e < n; ++e) a = fmaf(wx[e], R[(first + e) * 64 + c], a);
+      for (int e = 0; e < n; ++e) a = fmaf(wx[e], R[(first + e) * kAdjCg + c], a);
       tile[c * (kAdjTileW + 1) + xs] = a;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 64 * wt; i += 256) {
+    for (int i = threadIdx.x; i < kAdjCg * wt; i += 256) {
       const int cc = i / wt, xs = i - cc * wt;
       if (c0 + cc < m.C)
         out[(int64_t)(c0 + cc) * m.sc + (int64_t)(x0 + xs) * m.sw] = tile[cc * (kAdjTileW + 1) + xs];
@@ -1339,13 +1343,13 @@ hipError_t launch_img_grad_to_levels(const float* grad_img_map, int B, int map_s
       const float scx = map_size > 1 ? (float)(m.W - 1) / (float)(map_size - 1) : 0.f;
       int maxper = scx > 0.f ? (int)(2.f / scx) + 4 : map_size;
       if (maxper > map_size) maxper = map_size;
-      const size_t need = sizeof(float) * ((size_t)map_size * 64 + 64 * (size_t)(kAdjTileW + 1) + (size_t)map_size +
+      const size_t need = sizeof(float) * ((size_t)map_size * kAdjCg + kAdjCg * (size_t)(kAdjTileW + 1) + (size_t)map_size +
                                            (size_t)m.W * maxper) + sizeof(int) * 2 * (size_t)m.W;
       if (need > 150 * 1024) return hipErrorInvalidValue;
       if (need > lds) lds = need;
       const int k = lv.n++;
       lv.m[k] = m; lv.coff[k] = coff; lv.maxper[k] = maxper; lv.wg_begin[k] = (int)wgs;
-      wgs += (int64_t)B * m.H * ((m.C + 63) / 64);
+      wgs += (int64_t)B * m.H * ((m.C + kAdjCg - 1) / kAdjCg);
     }
     coff += m.C;
   }
