@@ -625,7 +625,7 @@ hipError_t launch_scatter_vox(const ScatterParams& sp, const FeatLayout& L, cons
                               const ScatterStreams& st) {
   (void)a;
   const int B = (int)((sp.g.p_begin + sp.g.n_valid + sp.g.N - 1) / sp.g.N);
-  int n_win_pk = 0;
+  int n_win_pk = 0, n_win_seen = 0;
   for (int l = 0; l < LIST_N_VOX_LEVELS; ++l) {
     const ListVoxLevel& gv = grad_vox[l];
     if (!gv.data) continue;
@@ -648,7 +648,11 @@ hipError_t launch_scatter_vox(const ScatterParams& sp, const FeatLayout& L, cons
       if (e != hipSuccess) return e;
       continue;
     }
-    hipStream_t s = (window_level && vb.mode != 2) ? st.window : st.direct;
+    // the first window level shares its stream with dW0, the second one goes behind the gathers on the caller's stream:
+    // with both behind the (contended) 2-ms dW0 the window stream ended 0.4 ms after the other two (forked backward
+    // 5.16 -> 4.98 ms)
+    hipStream_t s = st.direct;
+    if (window_level && vb.mode != 2) { s = n_win_seen == 0 ? st.window : st.gather; ++n_win_seen; }
 #ifndef LIST_BWD_NO_PK_ATOMICS
     // packed-half atomics (see k_scatter_vox_h2): fp16 operands, automatic form choice, C = 32 or a non-window C = 64
     // level, and the level's fp16 image fits the scratch the caller set aside
