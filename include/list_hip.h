@@ -320,6 +320,8 @@ typedef struct ListQueryGradArgs {
                                       /*   the LDS-window scatters and the gathers need different units, so they */
                                       /*   are forked onto these streams (event fork/join around them: the call  */
                                       /*   is still ordered on `stream` as a whole).  NULL: everything in order. */
+                                      /*   [1] carries dW0 and the 16^3 window level, the longest chain: create  */
+                                      /*   it with hipStreamCreateWithPriority(.., -1) (-0.06 ms per step).      */
   const ListMap2D* grad_img_levels;   /* optional: LIST_N_IMG_LEVELS descriptors as list_img_map_grad_to_levels   */
                                       /*   takes them.  The adjoint resize then runs inside this call, beside the */
                                       /*   voxel scatters still in flight on the auxiliary streams (needs         */

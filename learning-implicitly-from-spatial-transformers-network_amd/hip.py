@@ -508,7 +508,9 @@ class _AuxStreams:
             free = _aux_pool.setdefault(self.device.index, [])
             self.pair = free.pop() if free else None
         if self.pair is None:
-            self.pair = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
+            # the second stream carries dW0 and the 16^3 window level, the longest chain of the forked
+            # backward: at high priority its workgroups get compute units first (-0.06 ms, measured)
+            self.pair = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device, priority=-1))
         return self.pair
 
     def __exit__(self, *exc):
