@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 W_FLOP_PER_PT = 2 * (3610 * 512 + 512 * 256 + 256 * 256 + 256)      # 4 090 368
 W_BYTE_PER_PT = (7 * 8 * 369 + 4 * 1024) * 4 + 16                     # 99 056 fp32 maps
+DETAIL_STEPS = 3                 # untimed steps that time each gather on its own (run_config)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA
 
@@ -145,11 +146,18 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
     # one event set per row chunk of the call (ListQueryArgs.stage_event_sets): the intervals of all chunks are
     # summed, so kernel_ms is the time of ALL launches of a kernel in one step
     n_chunks = -(-B * N // 262144)
-    step_events = []
-    for _ in range(steps):
+    # timed region: the seven gathers of a chunk are independent launches, dispatched without the queue barrier between
+    # them (include/list_hip.h, ListStage), so no event is recorded between them -- their group is one interval,
+    # [SORT, TAIL]; their individual durations come from DETAIL_STEPS further steps after the timed region, with all
+    # events (which puts the barriers back)
+    apart = set(range(hip.STAGE_VOX0, hip.STAGE_IMG + 1))
+    def event_sets(coarse):
         pre = [ev.create() for _ in range(4)]
-        arr = (ctypes.c_void_p * (n_ev * n_chunks))(*[ev.create() for _ in range(n_ev * n_chunks)])
-        step_events.append((pre, arr))
+        arr = (ctypes.c_void_p * (n_ev * n_chunks))(
+            *[None if (coarse and i % n_ev in apart) else ev.create() for i in range(n_ev * n_chunks)])
+        return pre, arr
+    step_events = [event_sets(True) for _ in range(steps)]
+    detail_events = [event_sets(False) for _ in range(DETAIL_STEPS)]
     # N > 1: the exchange of step i (one RCCL all-gather of the SDF shards) runs on RCCL's stream beside the kernels
     # of step i+1; two output buffers alternate, and a step first orders itself after the gather that last read its buffer
     gathered = [torch.empty((world * B, N), dtype=torch.float32, device=device) for _ in range(2)] if world > 1 else None
@@ -218,16 +226,32 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
                          device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    for ev_set in detail_events:              # untimed: per-gather durations, the gathers one after the other
+        step(ev_set)
+    drain()
+    torch.cuda.synchronize()
     names = ["prep_img_resize_nhwc", "prep_vox_ndhwc", "prep_weights"] + list(hip.STAGE_NAMES)
     acc = np.zeros(len(names))
+    group = 0.0
+    first = hip.STAGE_VOX0 - 1                  # the event behind the point sort
+    def interval(arr, c, s0, s1):
+        return ev.elapsed_ms(ctypes.c_void_p(arr[c * n_ev + s0]), ctypes.c_void_p(arr[c * n_ev + s1]))
     for pre, arr in step_events:
         acc[0] += ev.elapsed_ms(pre[0], pre[1])
         acc[1] += ev.elapsed_ms(pre[1], pre[2])
         acc[2] += ev.elapsed_ms(pre[2], pre[3])
         for c in range(n_chunks):
+            group += interval(arr, c, first, hip.STAGE_IMG + 1)
             for s in range(n_ev - 1):
-                acc[3 + s] += ev.elapsed_ms(ctypes.c_void_p(arr[c * n_ev + s]), ctypes.c_void_p(arr[c * n_ev + s + 1]))
-    kernel_ms = dict(zip(names, (acc / steps).tolist()))
+                if s not in apart and s + 1 not in apart:
+                    acc[3 + s] += interval(arr, c, s, s + 1)
+    acc /= steps
+    for pre, arr in detail_events:
+        for c in range(n_chunks):
+            for s in range(first, hip.STAGE_IMG + 1):
+                acc[3 + s] += interval(arr, c, s, s + 1) / DETAIL_STEPS
+    kernel_ms = dict(zip(names, acc.tolist()))
+    kernel_ms["gathers_back_to_back"] = group / steps       # the same seven launches as they run in the timed region
     kernel_ms["_launches_per_step"] = n_chunks
     return elapsed, kernel_ms, sdfs[(n_calls[0] - 1) % len(sdfs)]
 
@@ -501,7 +525,7 @@ def main():
                                                                       2 if a16 else 4, proj=bool(inp.get("ordered_points"))),
                                       alt["precision"], args.workload)
         alt["path_roofs"] = path_roofs(alt["value"] / world, alt["precision"])
-    gather_ms = sum(v for k, v in kernel_ms.items() if k.startswith("gather_"))
+    gather_ms = kernel_ms["gathers_back_to_back"]       # the seven launches as the timed region runs them
     mlp_ms = kernel_ms["fc_0"] + kernel_ms["fc_1"] + kernel_ms["fc_2_out"]
     pmc = pmc_traffic(headline, args.workload)
     path = {
@@ -609,6 +633,10 @@ def main():
         "roofline": roof,
         "cpu_baseline": cpu,
         "kernel_ms": kernel_ms,
+        "kernel_ms_note": "HIP-event intervals over the timed steps, except gather_vox_l1 .. gather_tail: the seven "
+                          "gathers of a step are independent launches and run without queue barriers between them in "
+                          "the timed region (gathers_back_to_back is their group, timed there) and with the barriers "
+                          f"in {DETAIL_STEPS} further untimed steps, which is where their individual durations come from",
         "per_kernel": per_kernel,
         "path_rates": path,
         "parity_max_abs_err_vs_cpu": parity,

@@ -199,7 +199,11 @@ typedef struct ListQueryArgs {
 /* Boundaries recorded into ListQueryArgs.stage_events: one hipEvent after each kernel (group) of a
  * row chunk, so that the interval [i-1, i] of a set is the duration of kernel i for that chunk.  A query
  * above the chunk size runs ceil(B*N / list_query_chunk_rows()) chunks back to back: give one set per
- * chunk and sum the intervals over the sets for the time of the whole call. */
+ * chunk and sum the intervals over the sets for the time of the whole call.  Any handle may be NULL (that
+ * boundary is not recorded).  The seven gathers of a chunk are independent of each other and are dispatched without
+ * the queue barrier between them (hipExtAnyOrderLaunch behind the first one); a non-NULL handle among VOX0 .. IMG
+ * asks for their individual durations and puts the barriers back, which costs the step ~2 %: leave those six NULL to
+ * time the group as [SORT, TAIL]. */
 enum ListStage {
   LIST_STAGE_BEGIN = 0,   /* before the first kernel */
   LIST_STAGE_SORT = 1,    /* point ordering (histogram / scan / scatter, two passes) */

@@ -3,11 +3,28 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "list_hip.h"
 
 namespace list {
+
+// ---- independent launches -----------------------------------------------------------------------------------------
+// A stream keeps its kernels in order with the barrier bit of their AQL packets: each launch waits until every earlier
+// packet of the queue has drained and its caches are written back (~7 us of idle chip per boundary).  Launches that
+// do not depend on one another -- the seven gathers of a row chunk -- are therefore dispatched with
+// hipExtAnyOrderLaunch behind the first of their group: no barrier bit, the next kernel's workgroups follow the last
+// ones of the kernel before.  The next in-order launch waits for all of them, as for any earlier packet.
+// (Measured: this removes the boundaries, it does not run kernels of one queue side by side -- eight 16-workgroup
+// kernels launched this way still take eight times one; concurrency needs a second stream.)
+#ifdef LIST_LAUNCH_IN_ORDER
+constexpr int kAnyOrder = 0;
+#else
+constexpr int kAnyOrder = hipExtAnyOrderLaunch;
+#endif
+#define LIST_LAUNCH(kernel, grid, block, lds, s, order, ...) \
+  hipExtLaunchKernelGGL(kernel, grid, block, lds, s, nullptr, nullptr, (order), __VA_ARGS__)
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;

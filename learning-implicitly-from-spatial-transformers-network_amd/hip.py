@@ -97,6 +97,7 @@ BWD_STAGE_NAMES = ("head", "wgrad_fc2", "dgrad_fc2", "wgrad_fc1", "dgrad_fc1", "
                    "scatter_vox", "img_map_grad", "trans_mat_grad")
 
 N_STAGES = 13
+STAGE_VOX0, STAGE_IMG = 2, 7     # events VOX0 .. IMG lie between two gathers (include/list_hip.h, ListStage)
 # interval i = [event i, event i+1]: the kernel (group) that ends at stage i+1 of include/list_hip.h
 STAGE_NAMES = ("sort_points", "gather_vox_l1", "gather_vox_l2", "gather_vox_l3", "gather_vox_l4",
                "gather_vox_l5", "gather_img", "gather_tail", "fc_0", "exact_redo", "fc_1", "fc_2_out")
