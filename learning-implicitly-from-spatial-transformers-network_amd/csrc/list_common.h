@@ -14,8 +14,8 @@ namespace list {
 // A stream keeps its kernels in order with the barrier bit of their AQL packets: each launch waits until every earlier
 // packet of the queue has drained and its caches are written back (~7 us of idle chip per boundary).  Launches that
 // do not depend on one another -- the seven gathers of a row chunk -- are therefore dispatched with
-// hipExtAnyOrderLaunch behind the first of their group: no barrier bit, the next kernel's workgroups follow the last
-// ones of the kernel before.  The next in-order launch waits for all of them, as for any earlier packet.
+// hipExtAnyOrderLaunch behind the first of their group: no barrier bit, no drain / write-back / invalidate between
+// them.  The next in-order launch waits for all of them, as for any earlier packet.
 // (Measured: this removes the boundaries, it does not run kernels of one queue side by side -- eight 16-workgroup
 // kernels launched this way still take eight times one; concurrency needs a second stream.)
 #ifdef LIST_LAUNCH_IN_ORDER
