@@ -11,7 +11,6 @@ Queries above 262 144 points per call are cut along the point axis (one saved wo
 Query coordinates are data in the reference's training loop (train.py:82-85) and receive no gradient.
 """
 import torch
-import torch.nn.functional as F
 
 from .. import hip
 
