@@ -732,7 +732,7 @@ hipError_t launch_gather_fixup(const GatherParams& g, const FeatLayout& L, const
 // ---- launch ----------------------------------------------------------------------------------------
 // The gathers of one chunk write disjoint column ranges of X and read nothing another gather writes, so only the
 // first one keeps the stream's order (it waits for the point sort); the others are dispatched without the queue
-// barrier (list_common.h, LIST_LAUNCH / kAnyOrder): six drains of the chip less per chunk, 0.91 -> 0.86 ms for the
+// barrier (list_common.h, LIST_LAUNCH / any_order()): six drains of the chip less per chunk, 0.91 -> 0.86 ms for the
 // seven launches of the metric's shape.  `order` = 0 keeps the plain in-order launch (taken for all seven when the
 // caller asks for a stage event between two gathers: per-kernel timing).
 template <int C, int FMT, int F16>
@@ -773,7 +773,7 @@ static hipError_t launch_gather_fmt(const GatherParams& g, const FeatLayout& L, 
   };
   bool timed_apart = false;                             // an event between two gathers: they run one by one
   for (int st = LIST_STAGE_VOX0; st <= LIST_STAGE_IMG; ++st) timed_apart |= a.stage_events && a.stage_events[st];
-  const int side = timed_apart ? 0 : kAnyOrder;         // launches after the first one
+  const int side = timed_apart ? 0 : any_order();       // launches after the first one
   int order = 0;                                        // the first gather stays in stream order
   TailLevels tl;
   tl.n = 0;

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "list_hip.h"
 
@@ -18,10 +19,19 @@ namespace list {
 // them.  The next in-order launch waits for all of them, as for any earlier packet.
 // (Measured: this removes the boundaries, it does not run kernels of one queue side by side -- eight 16-workgroup
 // kernels launched this way still take eight times one; concurrency needs a second stream.)
+// LIST_LAUNCH_IN_ORDER (compile-time definition, or the environment variable of that name set to anything but "0"
+// when the library makes its first query): every launch in order, for A/B runs and as the switch to pull should a
+// runtime mishandle the flag.
 #ifdef LIST_LAUNCH_IN_ORDER
-constexpr int kAnyOrder = 0;
+inline int any_order() { return 0; }
 #else
-constexpr int kAnyOrder = hipExtAnyOrderLaunch;
+inline int any_order() {
+  static const int flag = [] {
+    const char* e = getenv("LIST_LAUNCH_IN_ORDER");
+    return (e && e[0] && !(e[0] == '0' && e[1] == 0)) ? 0 : (int)hipExtAnyOrderLaunch;
+  }();
+  return flag;
+}
 #endif
 #define LIST_LAUNCH(kernel, grid, block, lds, s, order, ...) \
   hipExtLaunchKernelGGL(kernel, grid, block, lds, s, nullptr, nullptr, (order), __VA_ARGS__)
