@@ -449,11 +449,13 @@ hipError_t launch_prep_weights_bwd(const ListMlpWeights& w, const FeatLayout& L,
   const int fmt = w.precision == LIST_PREC_FP16 ? FMT_FP16 : FMT_BF16_SPLIT;
   FeatLayout dummy;
   memset(&dummy, 0, sizeof(dummy));
+  int order = 0;          // three transposed copies, three parts of `packed`: only the first keeps the stream's order
   auto go = [&](const float* src, int Nout, int Kin_ref, int Krows, bool use_layout, size_t hi, size_t lo) {
     const int64_t total = (int64_t)Krows * Nout;
-    hipLaunchKernelGGL(k_prep_wt, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, Nout, Kin_ref,
-                       Krows, use_layout ? L : dummy, use_layout ? 1 : 0, fmt, (unsigned short*)(packed + hi),
-                       (unsigned short*)(packed + lo));
+    LIST_LAUNCH(k_prep_wt, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, order, src, Nout, Kin_ref,
+                Krows, use_layout ? L : dummy, use_layout ? 1 : 0, fmt, (unsigned short*)(packed + hi),
+                (unsigned short*)(packed + lo));
+    order = any_order();
   };
   go(w.w0, w.H1, w.F, P.KpT, true, P.w0t_hi, P.w0t_lo);
   go(w.w1, w.H2, w.H1, w.H1, false, P.w1t_hi, P.w1t_lo);

@@ -416,7 +416,7 @@ hipError_t launch_prep_weights(const ListMlpWeights& w, const FeatLayout& L, con
                                char* packed, hipStream_t s);
 hipError_t launch_split_xi(const float* x, unsigned short* out, int64_t n, hipStream_t s);
 hipError_t launch_split(const float* x, unsigned short* hi, unsigned short* lo, int64_t n, int fmt,
-                        hipStream_t s);
+                        hipStream_t s, int order = 0);
 struct SortBuffers { int* order; int* order_img; int* row_of; int* keys; int* keys2; int* bins; };
 hipError_t launch_sort_points(const GatherParams& g, const ListQueryArgs& a, const SortBuffers& sb,
                               hipStream_t s);

@@ -733,13 +733,13 @@ hipError_t launch_split_xi(const float* x, unsigned short* out, int64_t n, hipSt
 }
 
 hipError_t launch_split(const float* x, unsigned short* hi, unsigned short* lo, int64_t n, int fmt,
-                        hipStream_t s) {
+                        hipStream_t s, int order) {
   const int64_t n4 = n / 4;
   int64_t blocks = (n4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(k_split, dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)x, (uint2*)hi,
-                     (uint2*)lo, n4, fmt);
+  LIST_LAUNCH(k_split, dim3((unsigned)blocks), dim3(256), 0, s, order, (const float4*)x, (uint2*)hi,
+              (uint2*)lo, n4, fmt);
   return hipGetLastError();
 }
 
@@ -763,20 +763,21 @@ hipError_t launch_prep_weights(const ListMlpWeights& w, const FeatLayout& L, con
                                char* packed, hipStream_t s) {
   const int64_t n0 = (int64_t)w.H1 * L.Kp;
   const int fmt = w.precision == LIST_PREC_FP16 ? FMT_FP16 : FMT_BF16_SPLIT;
+  // four launches into four disjoint parts of `packed`: only the first keeps the stream's order (list_common.h)
   hipLaunchKernelGGL(k_prep_w0, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, s, w.w0, L, w.H1, fmt,
                      (unsigned short*)(packed + P.w0_hi), (unsigned short*)(packed + P.w0_lo));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   e = launch_split(w.w1, (unsigned short*)(packed + P.w1_hi), (unsigned short*)(packed + P.w1_lo),
-                   (int64_t)w.H2 * w.H1, fmt, s);
+                   (int64_t)w.H2 * w.H1, fmt, s, any_order());
   if (e != hipSuccess) return e;
   e = launch_split(w.w2, (unsigned short*)(packed + P.w2_hi), (unsigned short*)(packed + P.w2_lo),
-                   (int64_t)w.H3 * w.H2, fmt, s);
+                   (int64_t)w.H3 * w.H2, fmt, s, any_order());
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_copy_small, dim3((unsigned)((w.H1 + w.H2 + 2 * w.H3 + 1 + 255) / 256)), dim3(256), 0, s,
-                     w.b0, w.b1, w.b2, w.w3, w.b3, w.H1, w.H2, w.H3, (float*)(packed + P.b0),
-                     (float*)(packed + P.b1), (float*)(packed + P.b2), (float*)(packed + P.w3),
-                     (float*)(packed + P.b3));
+  LIST_LAUNCH(k_copy_small, dim3((unsigned)((w.H1 + w.H2 + 2 * w.H3 + 1 + 255) / 256)), dim3(256), 0, s, any_order(),
+              w.b0, w.b1, w.b2, w.w3, w.b3, w.H1, w.H2, w.H3, (float*)(packed + P.b0),
+              (float*)(packed + P.b1), (float*)(packed + P.b2), (float*)(packed + P.w3),
+              (float*)(packed + P.b3));
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   return hipSuccess;
