@@ -371,6 +371,11 @@ __device__ __forceinline__ SortKeys sort_keys(const GatherParams& g, const SortP
   return k;
 }
 
+__global__ __launch_bounds__(256) void k_zero_i32(int4* __restrict__ p, int n4) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) p[i] = make_int4(0, 0, 0, 0);
+}
+
 // Both orders are built by the same three launches: bins = [Morton counters | pixel counters].
 __global__ __launch_bounds__(256) void k_sort_hist(GatherParams g, SortParams sp, int* __restrict__ keys_m,
                                                    int* __restrict__ keys_p, int* __restrict__ bins_m,
@@ -456,7 +461,12 @@ hipError_t launch_sort_points(const GatherParams& g, const ListQueryArgs& a, con
   GatherParams raw = g;
   raw.order = nullptr;
   int* keys_m = sb.keys;
-  hipError_t e = hipMemsetAsync(sb.bins, 0, nbins * sizeof(int), s);
+  // the counters are cleared by a kernel of our own rather than hipMemsetAsync: nothing enqueued before it reads or
+  // writes them (the previous sort on this workspace finished before the gathers behind it started), so it goes out
+  // without the queue barrier (list_common.h) and the histogram launch is the sort's only wait on earlier work
+  LIST_LAUNCH(k_zero_i32, dim3((unsigned)((nbins / 4 + 255) / 256)), dim3(256), 0, s, any_order(), (int4*)sb.bins,
+              (int)(nbins / 4));
+  hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(256), 0, s, raw, sp, keys_m, sb.keys2, bins_m, bins_p);
   hipLaunchKernelGGL(k_sort_scan, dim3(img ? 2 * nslots : nslots), dim3(1024), 0, s, bins_m, bins_p, nslots, base);
