@@ -751,6 +751,7 @@ static hipError_t launch_vox_level_t(const GatherParams& g, const ListVoxLevel& 
   using G = VoxGeom<C, MapT<F16>::V>;
   const int big = lv.W > lv.H ? (lv.W > lv.D ? lv.W : lv.D) : (lv.H > lv.D ? lv.H : lv.D);
   const bool near = kDisp * 0.5f * (float)(big - 1) < 0.99f && C >= 16;   // stencil stays within one cell
+  if (near && gather_box_eligible(g, lv, col_off)) return launch_gather_vox_box(g, lv, col_off, s, order);
   if (near)
     LIST_LAUNCH((k_gather_vox_near<C, FMT, F16>), dim3(g.rows / G::RB), dim3(256), 0, s, order, g, lv, col_off);
   else
@@ -843,8 +844,11 @@ static hipError_t launch_gather_fmt(const GatherParams& g, const FeatLayout& L, 
   }
   // back to back without barriers: neighbours in the launch sequence share the chip at the boundary (digit = voxel
   // level, I = 2-D gather, T = tail; whatever the sequence does not name follows in level order).  Five sequences
-  // measured within 1 % of each other; the arithmetic-bound coarse levels first, then the 2-D gather, then the
-  // HBM-bound fine levels was the best
+  // measured within 1 % of each other in round 2; the coarse levels first, then the 2-D gather, then the HBM-bound
+  // fine levels was the best.  Round 3 (coarse levels on the matrix cores, gather_box_kernels.hip), eleven sequences on
+  // one device (tools/ab_gather.sh): with the coarse levels LAST the group takes 0.79-0.83 instead of 0.85-0.87 ms and
+  // fc_0 behind it 0.50-0.53 instead of 0.48 ms -- group + fc_0 = 1.34-1.35 ms whatever the order (the X lines the
+  // gathers leave dirty in the L2s drain into whatever runs next), the step 2.04-2.10 ms.  Kept: the round-2 order
   bool done[LIST_N_VOX_LEVELS + 2] = {false};
   for (const char* c = LIST_STR(LIST_GATHER_SEQ); ; ++c) {
     const bool rest = *c == 0;

@@ -425,6 +425,9 @@ hipError_t launch_gather(const GatherParams& g, const FeatLayout& L, const ListQ
                          int* nan_tiles, hipStream_t s);
 hipError_t launch_features_out(const GatherParams& g, const FeatLayout& L, float* out, int* nan_tiles,
                                hipStream_t s);
+// coarse levels on the matrix cores (gather_box_kernels.hip); eligible: near level, C = 128, fp16 maps and fp16 X
+bool gather_box_eligible(const GatherParams& g, const ListVoxLevel& lv, int col_off);
+hipError_t launch_gather_vox_box(const GatherParams& g, const ListVoxLevel& lv, int col_off, hipStream_t s, int order);
 // exact (reference skip semantics) redo of the voxel and 2-D gathers for the 256-row tiles flagged in tile_flags
 hipError_t launch_gather_fixup(const GatherParams& g, const FeatLayout& L, const ListQueryArgs& a,
                                const int* tile_flags, hipStream_t s);
