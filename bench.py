@@ -31,6 +31,10 @@ W_BYTE_PER_PT = (7 * 8 * 369 + 4 * 1024) * 4 + 16                     # 99 056 f
 DETAIL_STEPS = 3                 # untimed steps that time each gather on its own (run_config)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA
+PEAK_ATOMIC_GBS = 1300.0         # MI355X_MICROARCH.md, Global float atomics: chip-wide rate of added bytes (measured)
+# stated tolerances of the arithmetic modes against the fp32 reference
+TOLERANCE = {"fp16": {"kind": "relative", "bound": 1e-3, "of": "max|sdf| of the compared points"},
+             "bf16x3": {"kind": "absolute", "bound": 1e-4}, "bf16": {"kind": "absolute", "bound": 5e-3}}
 
 WORKLOADS = {
     # name: (B per GPU, N, img_res, vox_res, map_size, clamp_hi)
@@ -70,11 +74,14 @@ class HipEvents:
         return ms.value
 
 
-def make_inputs(workload, rank, device):
+def make_inputs(workload, rank, device, batch=None):
     """Synthetic inputs of SURVEY 8d, generated on the device (torch RNG, seed 333 + rank):
-    image maps N(0,1), voxel level 0 U(0,1), levels 1-5 N(0,1), queries U(-0.5,0.5)^3, synthetic camera."""
-    from oracle import synth            # shapes + exact weight/camera generators only
+    image maps N(0,1), voxel level 0 U(0,1), levels 1-5 N(0,1), queries U(-0.5,0.5)^3, synthetic camera.
+    `batch`: images of this rank (strong scaling: this rank's share of the global batch) instead of the workload's."""
+    from list_amd import synthetic as synth        # shapes + exact weight / camera generators (no oracle/ in the GPU leg)
     B, N, img_res, vox_res, map_size, clamp_hi = WORKLOADS[workload]
+    if batch is not None:
+        B = batch
     g = torch.Generator(device=device)
     g.manual_seed(333 + rank)
     img_maps = [torch.randn(s, generator=g, device=device) for s in synth.img_map_shapes(B, img_res)]
@@ -112,7 +119,7 @@ def kernel_table(B, N, img_res, vox_res, map_size, x_bytes_per_feature, map_byte
     CUs on this access pattern), never a fraction of the HBM peak; the HBM bytes of a gather
     come from the PMC counters (`hbm_bytes_pmc`, profiles/pmc_traffic.json)."""
     P = B * N
-    from oracle import synth
+    from list_amd import synthetic as synth
     vox_elems = [int(np.prod(s)) for s in synth.vox_map_shapes(B, vox_res)]
     img_elems_in = sum(int(np.prod(s)) for s in synth.img_map_shapes(B, img_res))
     img_elems_out = B * map_size * map_size * 1024
@@ -139,7 +146,7 @@ def kernel_table(B, N, img_res, vox_res, map_size, x_bytes_per_feature, map_byte
     return t
 
 
-def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gather_fn):
+def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gather_fn, sustained_steps=0):
     import torch.distributed as dist
     B, N = inp["B"], inp["N"]
     n_ev = hip.N_STAGES
@@ -152,7 +159,7 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
     # events (which puts the barriers back)
     apart = set(range(hip.STAGE_VOX0, hip.STAGE_IMG + 1))
     def event_sets(coarse):
-        pre = [ev.create() for _ in range(4)]
+        pre = [ev.create() for _ in range(5)]                  # [4]: behind the step's last launch
         arr = (ctypes.c_void_p * (n_ev * n_chunks))(
             *[None if (coarse and i % n_ev in apart) else ev.create() for i in range(n_ev * n_chunks)])
         return pre, arr
@@ -160,8 +167,12 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
     detail_events = [event_sets(False) for _ in range(DETAIL_STEPS)]
     # N > 1: the exchange of step i (one RCCL all-gather of the SDF shards) runs on RCCL's stream beside the kernels
     # of step i+1; two output buffers alternate, and a step first orders itself after the gather that last read its buffer
-    gathered = [torch.empty((world * B, N), dtype=torch.float32, device=device) for _ in range(2)] if world > 1 else None
-    sdfs = [torch.empty((B, N), dtype=torch.float32, device=device) for _ in range(2 if world > 1 else 1)]
+    # (strong scaling: the global batch may not divide by the ranks -- every rank exchanges a buffer of B_pad =
+    # ceil(B_global / world) images, of which it fills its own B)
+    B_pad = inp.get("B_pad", B)
+    gathered = [torch.empty((world * B_pad, N), dtype=torch.float32, device=device) for _ in range(2)] if world > 1 else None
+    sdf_bufs = [torch.zeros((B_pad, N), dtype=torch.float32, device=device) for _ in range(2 if world > 1 else 1)]
+    sdfs = [b[:B] for b in sdf_bufs]
     pending = [None, None]
     n_calls = [0]
     overlap_exchange = [True]
@@ -191,12 +202,13 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
         if world > 1:
             if overlap_exchange[0]:
                 try:
-                    _, pending[k] = gather_fn(sdf, out=gathered[k], async_op=True)
+                    _, pending[k] = gather_fn(sdf_bufs[k], out=gathered[k], async_op=True)
                 except (RuntimeError, TypeError) as e:          # no work handle from this backend build: in-line exchange
                     overlap_exchange[0] = False
                     print(f"bench: asynchronous all-gather unavailable ({e}); exchanging in line", file=sys.stderr)
             if not overlap_exchange[0]:
-                gather_fn(sdf, out=gathered[k])
+                gather_fn(sdf_bufs[k], out=gathered[k])
+        if pre: ev.record(pre[4])
         return sdf
 
     def drain():
@@ -225,7 +237,9 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
         t = torch.tensor([elapsed], dtype=torch.float64,
                          device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed_local, elapsed = elapsed, float(t.item())
+    else:
+        elapsed_local = elapsed
     for ev_set in detail_events:              # untimed: per-gather durations, the gathers one after the other
         step(ev_set)
     drain()
@@ -252,8 +266,45 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
                 acc[3 + s] += interval(arr, c, s, s + 1) / DETAIL_STEPS
     kernel_ms = dict(zip(names, acc.tolist()))
     kernel_ms["gathers_back_to_back"] = group / steps       # the same seven launches as they run in the timed region
+    kernel_ms["gathers_one_by_one_sum"] = float(sum(acc[3 + s] for s in range(first, hip.STAGE_IMG + 1)))   # (untimed steps)
     kernel_ms["_launches_per_step"] = n_chunks
-    return elapsed, kernel_ms, sdfs[(n_calls[0] - 1) % len(sdfs)]
+    # HIP-event time of every timed step (first launch .. behind the last one, on the stream they run on)
+    step_ms = sorted(ev.elapsed_ms(pre[0], pre[4]) for pre, _ in step_events)
+    q = lambda f: step_ms[min(len(step_ms) - 1, int(f * len(step_ms)))]
+    extra = {"elapsed_local_s": elapsed_local}
+    if world > 1:
+        # once, outside the timed region: what the exchange delivered holds this rank's shard at this rank's offset, and
+        # every other rank's rows are finite numbers (not the zeros the buffer was born with)
+        rank = dist.get_rank()
+        kk = (n_calls[0] - 1) % len(sdfs)
+        got = gathered[kk]
+        own_ok = bool(torch.equal(got[rank * B_pad: rank * B_pad + B], sdfs[kk]))
+        finite = bool(torch.isfinite(got).all())
+        filled = all(bool((got[r * B_pad] != 0).any()) for r in range(world))
+        extra["exchange_check"] = {"own_shard_at_own_offset": own_ok, "all_finite": finite,
+                                   "every_rank_delivered": filled, "rows_per_rank_in_buffer": B_pad}
+        assert own_ok and finite and filled, extra["exchange_check"]
+    extra["step_events_ms"] = {"median": q(0.5), "p10": q(0.1), "p90": q(0.9), "min": step_ms[0], "max": step_ms[-1],
+                                    "n": len(step_ms)}
+    last = sdfs[(n_calls[0] - 1) % len(sdfs)]
+    if sustained_steps > 0:
+        # untimed-in-headline: the clock the chip settles to under the load (a 20-step burst is 40 ms).  Same step,
+        # `sustained_steps` times back to back; stage events on the last 16 steps only
+        ring = [event_sets(True) for _ in range(16)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(sustained_steps):
+            step(ring[i - (sustained_steps - 16)] if i >= sustained_steps - 16 else None)
+        drain()
+        torch.cuda.synchronize()
+        s_el = time.perf_counter() - t0
+        fc0 = sum(interval(arr, c, hip.STAGE_NAMES.index("fc_0"), hip.STAGE_NAMES.index("fc_0") + 1)
+                  for _, arr in ring for c in range(n_chunks)) / len(ring)
+        st = sorted(ev.elapsed_ms(pre[0], pre[4]) for pre, _ in ring)
+        extra["sustained"] = {"steps": sustained_steps, "seconds": s_el, "ms_per_step": s_el / sustained_steps * 1e3,
+                                   "value_per_gpu": B * N * sustained_steps / s_el, "fc_0_ms": fc0,
+                                   "step_events_median_ms_last16": st[len(st) // 2]}
+    return elapsed, kernel_ms, last, extra
 
 
 def run_train_step(precision, steps, warmup, inp, hip, ev):
@@ -300,7 +351,44 @@ def run_train_step(precision, steps, warmup, inp, hip, ev):
         fwd_ms += ev.elapsed_ms(e[0], e[1])
         bwd_ms += ev.elapsed_ms(e[1], e[2])
     kernel_ms = dict(zip(hip.BWD_STAGE_NAMES, (acc / steps).tolist()))
+    # per-stage durations with the stages IN LINE on one stream (3 untimed steps): what each kernel group takes on its
+    # own -- the forked step above overlaps them, so its main-stream intervals are not kernel times
+    inl = np.zeros(n_ev - 1)
+    for _ in range(3):
+        arr = (ctypes.c_void_p * n_ev)(*[ev.create() for _ in range(n_ev)])
+        img = hip.prep_img_maps(inp["img_maps"], inp["map_size"], md)
+        vox = hip.prep_vox_maps(inp["vox_maps"], md)
+        packed = hip.prep_mlp_weights(inp["weights"], vox.channels, img.channels, precision)
+        packed_b = hip.prep_mlp_weights_bwd(inp["weights"], vox.channels, img.channels, precision)
+        _, ctx = hip.sdf_query(inp["query"], inp["trans_mat"], img, vox, packed, precision=precision,
+                               save_for_backward=True, clamp_hi=inp["clamp_hi"])
+        hip.sdf_query_backward(ctx, gsdf, packed_b, stage_events=arr, img_levels_like=inp["img_maps"], overlap=False)
+        torch.cuda.synchronize()
+        for s in range(n_ev - 1):
+            inl[s] += ev.elapsed_ms(ctypes.c_void_p(arr[s]), ctypes.c_void_p(arr[s + 1])) / 3
+    inline_ms = dict(zip(hip.BWD_STAGE_NAMES, inl.tolist()))
+    P = B * N
+    flop0 = P * 2 * 3610 * 512
+    dom = max(("dgrad_fc0", "wgrad_fc0"), key=lambda k: inline_ms[k])
+    products = 3 if precision == "bf16x3" else 1
+    ach = flop0 / (inline_ms[dom] * 1e-3) / 1e12
+    # bytes the three direct (global-atomic) voxel levels add: 56 taps x C channels per point, fp32 -- the 64^3 x 32 level
+    # as packed halfs with fp16 operands; the window levels' flushes and the gathered 32^3 level come on top
+    direct = P * 56 * (1 * 4 + 16 * 4 + 32 * (2 if precision == "fp16" else 4))
+    roofline = {"kernel": {"dgrad_fc0": "k_gemm_nt_pp / k_gemm_nt16 (dX = dZ1 . W0)", "wgrad_fc0": "k_gemm_tn (dW0 = dZ1^T . X)"}[dom],
+                "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
+                "traffic": None, "launch_ms": inline_ms[dom], "algorithmic_flop_per_launch": flop0,
+                "mfma_products_per_mac": products, "timed": "in line on one stream, 3 untimed steps (stage events)",
+                "other_stage": {"stage": "scatter_vox (in line)", "ms": inline_ms["scatter_vox"],
+                                "bound": "hbm: global float atomics", "peak": PEAK_ATOMIC_GBS, "unit": "GB/s of added bytes",
+                                "direct_levels_atomic_bytes": direct,
+                                "achieved_lower_bound": direct / (inline_ms["scatter_vox"] * 1e-3) / 1e9,
+                                "frac_lower_bound": direct / (inline_ms["scatter_vox"] * 1e-3) / 1e9 / PEAK_ATOMIC_GBS,
+                                "note": "the stage also holds the two LDS-window levels (flush atomics, data dependent) "
+                                        "and the voxel-side gather of the 32^3 level: the fraction is a lower bound"}}
+    assert 0.0 < roofline["frac"] <= 1.0
     return {"precision": precision, "steps": steps, "ms_per_step": elapsed / steps * 1e3,
+            "roofline": roofline, "kernel_ms_inline": inline_ms,
             "value": B * N * steps / elapsed, "unit": "query-points/s (forward + backward)",
             "forward_query_ms": fwd_ms / steps, "backward_ms": bwd_ms / steps,
             "kernel_ms": kernel_ms,
@@ -368,7 +456,13 @@ def pmc_traffic(precision, workload):
     tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if workload != "list_im2sdf_b8_n20k_224" or not os.path.exists(tf):
         return {}
-    return json.load(open(tf)).get(precision, {})
+    data = json.load(open(tf))
+    # the counters belong to the kernel sources they were collected on (tools/pmc_traffic.py stamps build.py's SHA-256):
+    # stale numbers are dropped, never replayed
+    from list_amd import build as _build
+    if data.get("_source_fingerprint") != _build._fingerprint():
+        return {}
+    return data.get(precision, {})
 
 
 def roofline_of(kernel_ms, table, precision, workload):
@@ -421,6 +515,12 @@ def main():
     ap.add_argument("--no-train-step", action="store_true")
     ap.add_argument("--whole-model", action="store_true",
                     help="also time the whole LIST.forward (encoders included) on the same B x N")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank owns the workload's B images (BASELINE config 2 per GPU); strong: BASELINE "
+                         "config 3 -- a global batch of --global-batch images split over the ranks")
+    ap.add_argument("--global-batch", type=int, default=64)
+    ap.add_argument("--sustained-steps", type=int, default=1000,
+                    help="length of the sustained leg behind the timed region (0: none); reported, never the headline")
     ap.add_argument("--cpu-sample-images", type=int, default=2)
     ap.add_argument("--cpu-sample-points", type=int, default=50000,
                     help="points per image of the CPU baseline sample (bounds the 256^3 grid workload)")
@@ -455,18 +555,32 @@ def main():
     else:
         ge.build()
     from list_amd import hip
-    from list_amd.parallel import gather_sdf_shards
+    from list_amd.parallel import gather_sdf_shards, shard_range
+    gather_fn = gather_sdf_shards
 
-    inp = make_inputs(args.workload, rank, device)
+    b_local = None
+    if args.scaling == "strong":
+        # BASELINE config 3: B_global images split over the ranks (contiguous, balanced; the first
+        # B_global % world ranks own one more)
+        if args.workload != "list_im2sdf_b8_n20k_224":
+            raise SystemExit("--scaling strong is BASELINE config 3: the list_im2sdf_b8_n20k_224 shapes")
+        if args.global_batch < world:
+            raise SystemExit(f"--global-batch {args.global_batch} cannot be split over {world} ranks")
+        b0, b1 = shard_range(args.global_batch, rank, world)
+        b_local = b1 - b0
+    inp = make_inputs(args.workload, rank, device, batch=b_local)
+    if args.scaling == "strong":
+        inp["B_pad"] = -(-args.global_batch // world)
     B, N = inp["B"], inp["N"]
+    global_points = args.global_batch * N if args.scaling == "strong" else world * B * N
     _, _, img_res, vox_res, map_size, _ = WORKLOADS[args.workload]
     ev = HipEvents()
     # config 4 (256^3 inference grid) is stated in fp32: its headline is the fp32-grade bf16x3 arithmetic, fp16 the alt
     grid = args.workload.startswith("list_grid")
     headline = args.precision or ("bf16x3" if grid else "fp16")
     alt_prec = "fp16" if headline == "bf16x3" else "bf16x3"
-    elapsed, kernel_ms, sdf = run_config(args, headline, args.steps, args.warmup, inp, hip, ev, world,
-                                         device, gather_sdf_shards)
+    elapsed, kernel_ms, sdf, extra = run_config(args, headline, args.steps, args.warmup, inp, hip, ev, world,
+                                                device, gather_fn, sustained_steps=args.sustained_steps)
     alt_cl = None
     if args.precision is None and not args.no_channels_last_alt:
         # same workload with the maps already in the layout MI355X-first producers emit (SURVEY 8 f2:
@@ -476,18 +590,18 @@ def main():
         inp_cl["img_maps"] = [m.contiguous(memory_format=torch.channels_last) for m in inp["img_maps"]]
         inp_cl["vox_maps"] = [m.contiguous(memory_format=torch.channels_last_3d) for m in inp["vox_maps"]]
         c_steps = max(2, args.steps // 2)
-        c_el, c_ms, c_sdf = run_config(args, headline, c_steps, min(args.warmup, 2), inp_cl, hip, ev, world,
-                                       device, gather_sdf_shards)
+        c_el, c_ms, c_sdf, _ = run_config(args, headline, c_steps, min(args.warmup, 2), inp_cl, hip, ev, world,
+                                          device, gather_fn)
         alt_cl = {"inputs": "channels_last / channels_last_3d fp32 maps resident in HBM", "precision": headline,
-                  "value": world * B * N * c_steps / c_el, "steps": c_steps, "ms_per_step": c_el / c_steps * 1e3,
+                  "value": global_points * c_steps / c_el, "steps": c_steps, "ms_per_step": c_el / c_steps * 1e3,
                   "kernel_ms": c_ms, "max_abs_diff_vs_headline": float((c_sdf - sdf).abs().max())}
         del inp_cl
     alt = None
     if args.precision is None:
         a_steps = max(2, args.steps // 2)
-        a_el, a_ms, a_sdf = run_config(args, alt_prec, a_steps, min(args.warmup, 2), inp, hip, ev, world,
-                                       device, gather_sdf_shards)
-        alt = {"precision": alt_prec, "value": world * B * N * a_steps / a_el, "steps": a_steps,
+        a_el, a_ms, a_sdf, a_extra = run_config(args, alt_prec, a_steps, min(args.warmup, 2), inp, hip, ev, world,
+                                                device, gather_fn)
+        alt = {"precision": alt_prec, "value": global_points * a_steps / a_el, "steps": a_steps,
                "ms_per_step": a_el / a_steps * 1e3, "kernel_ms": a_ms,
                "max_abs_diff_vs_headline": float((a_sdf - sdf).abs().max())}
 
@@ -498,7 +612,7 @@ def main():
         # the same training step with fp32-grade gradients (bf16 hi+lo operands): the parity-grade number
         t3, _ = run_train_step("bf16x3", max(2, args.steps // 4), min(args.warmup, 2), inp, hip, ev)
         train["fp32_grade"] = {k: t3[k] for k in ("precision", "steps", "ms_per_step", "value", "forward_query_ms",
-                                                  "backward_ms", "kernel_ms")}
+                                                  "backward_ms", "kernel_ms", "kernel_ms_inline", "roofline")}
         train["gradient_precision_note"] = (
             "fp16 operands flip ~1e-3 of the ReLU masks: gradients carry 2-4 % relative L2 noise against the "
             "reference's autograd (grad_rel_l2_vs_cpu); the bf16x3 step reproduces them to 1.5e-5 of each tensor's "
@@ -508,13 +622,29 @@ def main():
     if args.whole_model and rank == 0:
         whole = run_whole_model(args.workload, headline, device)
 
+    ranks = None
+    if world > 1:
+        # what the collective backend really spans: every rank's id and timed-region wall clock through an all-gather
+        # round trip (nccl = RCCL on device tensors; the gloo rehearsal stages through the host)
+        on = device if dist.get_backend() == "nccl" else "cpu"
+        mine = torch.tensor([float(rank), extra["elapsed_local_s"], float(B)], dtype=torch.float64, device=on)
+        allr = torch.empty((world * 3,), dtype=torch.float64, device=on)
+        dist.all_gather_into_tensor(allr, mine)
+        allr = allr.cpu().reshape(world, 3)
+        ms = allr[:, 1] / args.steps * 1e3
+        ranks = {"backend": dist.get_backend(), "rccl_ranks_observed": int(len(set(int(x) for x in allr[:, 0].tolist()))),
+                 "world_size": dist.get_world_size(), "images_per_rank": [int(x) for x in allr[:, 2].tolist()],
+                 "ms_per_step_per_rank": {"min": float(ms.min()), "max": float(ms.max()),
+                                          "all": [round(float(x), 4) for x in ms.tolist()]},
+                 "exchange_check": extra.get("exchange_check")}
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
     P = B * N
-    value = world * P * args.steps / elapsed
+    value = global_points * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
     xb = 2 if headline != "bf16x3" else 4
     table = kernel_table(B, N, img_res, vox_res, map_size, xb, 2 if headline == "fp16" else 4, proj=bool(inp.get("ordered_points")))
@@ -524,13 +654,13 @@ def main():
         alt["roofline"] = roofline_of(alt["kernel_ms"], kernel_table(B, N, img_res, vox_res, map_size, 2 if a16 else 4,
                                                                       2 if a16 else 4, proj=bool(inp.get("ordered_points"))),
                                       alt["precision"], args.workload)
-        alt["path_roofs"] = path_roofs(alt["value"] / world, alt["precision"])
+        alt["path_roofs"] = path_roofs(alt["value"] * P / global_points, alt["precision"])
     gather_ms = kernel_ms["gathers_back_to_back"]       # the seven launches as the timed region runs them
     mlp_ms = kernel_ms["fc_0"] + kernel_ms["fc_1"] + kernel_ms["fc_2_out"]
     pmc = pmc_traffic(headline, args.workload)
     path = {
         # the whole path against its binding roof (per GPU)
-        **path_roofs(value / world, headline),
+        **path_roofs(value * P / global_points, headline),      # rank 0's share
         "mlp_TFLOPs_algorithmic": P * W_FLOP_PER_PT / (mlp_ms * 1e-3) / 1e12,
         "mlp_frac_of_bf16_peak": P * W_FLOP_PER_PT / (mlp_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
         "gather_ms": gather_ms, "mlp_ms": mlp_ms,
@@ -545,6 +675,8 @@ def main():
         if kernel_ms.get(k, 0) <= 0:
             continue
         e = {"ms": kernel_ms[k], "bound": b, "units": what}
+        if k.startswith("gather_"):
+            e["timed_apart"] = True        # from the untimed detail steps (barriers between the gathers), not the timed region
         if b == "mfma":
             e["TFLOPs"] = u / (kernel_ms[k] * 1e-3) / 1e12
             e["frac_of_mfma_peak"] = e["TFLOPs"] / PEAK_BF16_TFLOPS
@@ -561,6 +693,8 @@ def main():
     # ---- CPU baseline (oracle, torch-op restatement) on a bounded sample ---------------------------
     cpu = None
     parity = None
+    parity_leg = None
+    modes = {}
     if not args.no_cpu_baseline and world == 1:
         from oracle import torch_ops as TO
         ns = min(args.cpu_sample_images, B)
@@ -585,8 +719,38 @@ def main():
                    "sample": f"{ns} of {B} images x {cq.shape[1]} of {N} points, oracle/torch_ops.py (the reference's torch "
                              f"op sequence, fp32, no_grad), median of 3 after 1 warm-up, torch "
                              f"{torch.__version__}, os.cpu_count()={os.cpu_count()}"}
-            parity = float((sdf[:ns, :cq.shape[1]].cpu() - ref).abs().max())
-            assert parity < 1e-4, f"parity bound violated: {parity}"
+            # ---- parity, magnitude-aware (the fp16 mode's error is RELATIVE, ~7e-4 of max|sdf|; bf16x3's is fp32-grade) --
+            # leg 1: the benched distribution (|sdf| <~ 0.06 with the SURVEY 8d weights); leg 2: every weight and bias of
+            # the MLP times 1.74, which takes |sdf| to ~0.5 -- what a trained LIST emits on a unit box (sdf_scale 1.0,
+            # arguments.py:54).  Stated tolerances: fp16 1e-3 x max|sdf|, bf16x3 1e-4 absolute; both asserted here.
+            md_of = hip.map_dtype_for
+            def forward(prec, weights):
+                img_p = hip.prep_img_maps(inp["img_maps"], inp["map_size"], md_of(prec))
+                vox_p = hip.prep_vox_maps(inp["vox_maps"], md_of(prec))
+                pk = hip.prep_mlp_weights(weights, vox_p.channels, img_p.channels, prec)
+                pj = hip.prep_percep_proj(img_p, pk, prec) if inp.get("ordered_points") else None
+                o = hip.sdf_query(inp["query"], inp["trans_mat"], img_p, vox_p, pk, precision=prec,
+                                  clamp_hi=inp["clamp_hi"], sort_points=not inp.get("ordered_points", False), percep_proj=pj)
+                torch.cuda.synchronize()
+                return o[:ns, :cq.shape[1]].cpu()
+            def leg(got, want):
+                e, m = float((got - want).abs().max()), float(want.abs().max())
+                return {"max_abs_err": e, "max_abs_sdf": m, "rel_err": e / m, "holds_1e-4_absolute": e < 1e-4}
+            big_w = {k: v * 1.74 for k, v in inp["weights"].items()}
+            ref_big = TO.list_query(cq, ci, cv, ct, {k: v.cpu() for k, v in big_w.items()}, **kw)
+            tolerance = TOLERANCE
+            modes = {}
+            for prec in dict.fromkeys([headline, alt_prec] if args.precision is None else [headline]):
+                legs = {"bench_distribution": leg(forward(prec, inp["weights"]), ref),
+                        "sdf_about_0.5": leg(forward(prec, big_w), ref_big)}
+                tol = tolerance[prec]
+                for name, l in legs.items():
+                    l["within_stated_tolerance"] = (l["rel_err"] < tol["bound"]) if tol["kind"] == "relative" \
+                        else (l["max_abs_err"] < tol["bound"])
+                    assert l["within_stated_tolerance"], (prec, name, l)
+                modes[prec] = {"stated_tolerance": tol, "parity_vs_cpu": legs}
+            parity_leg = leg(sdf[:ns, :cq.shape[1]].cpu(), ref)
+            parity = parity_leg["max_abs_err"]
             if train is not None and inp["map_size"] == 137:
                 # the same training step through torch autograd on the host (1 image), and the agreement of
                 # two gradients that depend on no ReLU mask / on every mask
@@ -606,6 +770,12 @@ def main():
                     "d_trans_mat[0]": float((got_T - cg["d_trans_mat"]).norm() / cg["d_trans_mat"].norm()),
                     "d_vox5[0]": float((got_v5 - cg["d_vox5"]).norm() / cg["d_vox5"].norm())}
 
+    perf = {headline: {"value": value, "ms_per_step": ms_per_step, "roofline_frac": roof["frac"]}}
+    if alt is not None:
+        perf[alt["precision"]] = {"value": alt["value"], "ms_per_step": alt["ms_per_step"],
+                                  "roofline_frac": alt["roofline"]["frac"]}
+    for prec, pf in perf.items():
+        modes.setdefault(prec, {"stated_tolerance": TOLERANCE[prec], "parity_vs_cpu": None}).update(pf)
     arith = {"bf16x3": "bf16 hi/lo split operands, 3 MFMA products per MAC, fp32 accumulate",
              "fp16": "fp16 operands (saturating), 1 MFMA product per MAC, fp32 accumulate",
              "bf16": "bf16 operands, 1 MFMA product per MAC, fp32 accumulate"}
@@ -614,11 +784,13 @@ def main():
                   else "SDF query-points/sec",
         "value": value, "unit": "query-points/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None,
+        "scaling": args.scaling, "vs_baseline": None,
         "dtype": {"fp16": "fp16", "bf16": "bf16", "bf16x3": "bf16x3 (bf16 hi+lo operands, fp32-grade)"}[headline],
         "data": "synthetic",
-        "config": {"workload": args.workload, "images_per_gpu": B, "points_per_image": N,
-                   "global_points_per_step": world * P, "precision": headline,
+        "config": {"workload": args.workload if args.scaling == "weak" else f"list_im2sdf_b{args.global_batch}_n20k_224 (BASELINE config 3)",
+                   "images_per_gpu": B, "points_per_image": N,
+                   "global_batch": args.global_batch if args.scaling == "strong" else world * B,
+                   "global_points_per_step": global_points, "precision": headline,
                    "point_sort": ("skipped: raster-ordered grid, as executors.LIST.predict_grid queries it"
                                   if inp.get("ordered_points") else "Morton + pixel counting sort inside the step"),
                    "perceptual_block": ("projected through fc_0 once per image (list_prep_percep_proj, inside the step), "
@@ -630,6 +802,9 @@ def main():
                    "inputs": "reference layout (NCHW/NCDHW fp32) resident in HBM; layout hand-off + weight "
                              "repack inside the timed step",
                    "parallelism": f"batch-sharded x{world}" + (" + RCCL all-gather of sdf" if world > 1 else "")},
+        "ranks": ranks,
+        "step_events_ms": extra["step_events_ms"],
+        "sustained": extra.get("sustained"),
         "roofline": roof,
         "cpu_baseline": cpu,
         "kernel_ms": kernel_ms,
@@ -640,7 +815,12 @@ def main():
         "per_kernel": per_kernel,
         "path_rates": path,
         "parity_max_abs_err_vs_cpu": parity,
-        "parity_bound": 1e-4,
+        "parity_max_abs_sdf": parity_leg["max_abs_sdf"] if parity_leg else None,
+        "parity_rel_err": parity_leg["rel_err"] if parity_leg else None,
+        "parity_bound": ({"fp16": "1e-3 x max|sdf| (relative: the mode rounds features and activations to 11 bits; 1e-4 "
+                                  "absolute holds only while |sdf| <~ 0.12 -- see modes.fp16.parity_vs_cpu)",
+                          "bf16x3": "1e-4 absolute (fp32-grade at every magnitude)", "bf16": "5e-3 absolute"}[headline]),
+        "modes": modes,
         "speedup_vs_cpu": (value / cpu["value"]) if cpu else None,
         "alt": alt,
         "alt_channels_last_inputs": alt_cl,

@@ -461,10 +461,11 @@ hipError_t launch_sort_points(const GatherParams& g, const ListQueryArgs& a, con
   GatherParams raw = g;
   raw.order = nullptr;
   int* keys_m = sb.keys;
-  // the counters are cleared by a kernel of our own rather than hipMemsetAsync: nothing enqueued before it reads or
-  // writes them (the previous sort on this workspace finished before the gathers behind it started), so it goes out
-  // without the queue barrier (list_common.h) and the histogram launch is the sort's only wait on earlier work
-  LIST_LAUNCH(k_zero_i32, dim3((unsigned)((nbins / 4 + 255) / 256)), dim3(256), 0, s, any_order(), (int4*)sb.bins,
+  // the counters are cleared by a kernel of our own rather than hipMemsetAsync (one launch instead of a memset node),
+  // dispatched IN STREAM ORDER: the workspace is the caller's, and a stream-ordered allocator may hand out a block
+  // whose previous owner's kernel is still running -- a clear without the queue barrier (tried in round 2 for
+  // ~0.01 ms) could then write zeros into that kernel's live memory
+  LIST_LAUNCH(k_zero_i32, dim3((unsigned)((nbins / 4 + 255) / 256)), dim3(256), 0, s, 0, (int4*)sb.bins,
               (int)(nbins / 4));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;

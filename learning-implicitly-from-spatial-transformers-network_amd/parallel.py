@@ -58,6 +58,28 @@ def gather_sdf_shards(sdf_local, out=None, group=None, async_op=False):
     return (out, None) if async_op else out
 
 
+def gather_batch_ragged(sdf_local, batch_global, group=None):
+    """All-gather of BATCH-axis shards produced with shard_range when the global batch does not divide by the ranks
+    (strong scaling, BASELINE config 3 split over 1 / 2 / 4 / 8 ranks and anything in between): every rank sends a
+    buffer of ceil(batch_global / world) images of which it fills its own, the result is trimmed to
+    [batch_global, N] in rank order.  The same padded exchange bench.py --scaling strong keeps in its timed step."""
+    rank, world = world_info(group)
+    if world == 1:
+        return sdf_local
+    b_pad = -(-batch_global // world)
+    b, e = shard_range(batch_global, rank, world)
+    if sdf_local.shape[0] != e - b:
+        raise RuntimeError(f"rank {rank} owns images [{b}, {e}) of {batch_global}, got {sdf_local.shape[0]}")
+    buf = torch.zeros((b_pad,) + tuple(sdf_local.shape[1:]), dtype=sdf_local.dtype, device=sdf_local.device)
+    buf[: e - b] = sdf_local
+    allb = gather_sdf_shards(buf, group=group)
+    parts = []
+    for r in range(world):
+        rb, re = shard_range(batch_global, r, world)
+        parts.append(allb[r * b_pad: r * b_pad + (re - rb)])
+    return torch.cat(parts)
+
+
 def gather_ragged_points(values_local, total, group=None):
     """All-gather of ragged 1-D shards produced with shard_range (query-axis partition of one
     image's grid): pads to the largest shard, gathers, and trims -> [total]."""

@@ -41,6 +41,18 @@ def _worker(rank, world, port, out_dir):
         assert (e - b) == (19 if rank == 0 else 18)
         whole = P.gather_ragged_points(grid_vals[b:e].clone(), 37)
         assert torch.equal(whole, grid_vals)
+        # strong scaling (BASELINE config 3): a global batch split over the ranks, ragged when it does not divide
+        for bg in (5, 7, 64, 2):
+            full = torch.randn((bg, 11), generator=torch.Generator().manual_seed(100 + bg))
+            b, e = P.shard_range(bg, rank, world)
+            assert (e - b) == bg // world + (1 if rank < bg % world else 0)
+            assert sum(P.shard_range(bg, r, world)[1] - P.shard_range(bg, r, world)[0] for r in range(world)) == bg
+            assert torch.equal(P.gather_batch_ragged(full[b:e].clone(), bg), full)
+        # the per-rank arithmetic of bench.py --scaling strong at the driver's rank counts
+        for w in (1, 2, 4, 8, 3):
+            shards = [P.shard_range(64, r, w) for r in range(w)]
+            assert shards[0][0] == 0 and shards[-1][1] == 64 and all(a[1] == b2[0] for a, b2 in zip(shards, shards[1:]))
+            assert max(e2 - b2 for b2, e2 in shards) == -(-64 // w)
         _check_training_loss_and_gradients(rank, world)
         _check_broadcast(rank)
         np.save(os.path.join(out_dir, f"ok_{rank}.npy"), np.array([1]))

@@ -9,7 +9,7 @@ import torch
 sys.path.insert(0, ".")
 from list_amd import arguments, utils          # noqa: E402
 from list_amd.train import _Module              # noqa: E402
-from oracle import synth                        # noqa: E402
+from list_amd import synthetic as synth                        # noqa: E402
 
 dev = torch.device("cuda:0")
 res = int(sys.argv[1]) if len(sys.argv) > 1 else 256

@@ -39,6 +39,9 @@ def kernel_key(name, grid, seq):
             lvl = "l4" if seq[(k, c)] % 2 == 0 else "l5"
             seq[(k, c)] += 1
         return "gather_vox_" + lvl
+    if k == "k_gather_vox_box":               # coarse levels on the matrix cores: <C, LDS box rows>; the 16^3 level has the big box
+        rows = int(t.strip("<>").split(",")[1])
+        return "gather_vox_l4" if rows > 128 else "gather_vox_l5"
     return {"k_gather_img": "gather_img", "k_gather_tail": "gather_tail",
             "k_transpose_vox_tile": "prep_vox_ndhwc", "k_transpose_vox": "prep_vox_ndhwc",
             "k_transpose_vox_fused": "prep_vox_ndhwc_fused", "k_prep_img_rows": "prep_img_resize_nhwc_rows",
@@ -86,6 +89,14 @@ def main():
                   "write_size_kb_raw": w_kb, "fetch_correction": 2.0,
                   "uncalibrated_writes": k == "fc_2_out" or k.startswith("gather")}
     data = json.load(open(out)) if os.path.exists(out) else {}
+    # what the counters were measured ON: the SHA-256 of the kernel sources (build.py); bench.py drops `traffic` when
+    # the library it runs was built from other sources
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from list_amd import build as _build
+    fp = _build._fingerprint()
+    if data.get("_source_fingerprint") != fp:
+        data = {}
+    data["_source_fingerprint"] = fp
     data[precision] = res
     json.dump(data, open(out, "w"), indent=1, sort_keys=True)
     for k, v in res.items():

@@ -9,7 +9,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from list_amd import hip            # noqa: E402
-from oracle import synth             # noqa: E402
+from list_amd import synthetic as synth             # noqa: E402
 
 dev = torch.device("cuda:0")
 B = 8
