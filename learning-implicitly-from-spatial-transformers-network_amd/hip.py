@@ -183,10 +183,20 @@ def load():
     return _lib
 
 
+class ListError(RuntimeError):
+    """A call into liblist_hip.so returned a non-zero ListStatus (include/list_hip.h); `code` is that status."""
+
+    def __init__(self, what, code, msg):
+        super().__init__(f"{what} failed ({code}): {msg}")
+        self.what, self.code = what, int(code)
+
+
+ERR_ARG, ERR_SHAPE, ERR_WORKSPACE, ERR_HIP, ERR_UNSUPPORTED = -1, -2, -3, -4, -5      # enum ListStatus
+
+
 def _check(rc, what):
     if rc != 0:
-        msg = load().list_last_error().decode("utf-8", "replace")
-        raise RuntimeError(f"{what} failed ({rc}): {msg}")
+        raise ListError(what, rc, load().list_last_error().decode("utf-8", "replace"))
 
 
 def _stream():

@@ -231,8 +231,8 @@ def sdf_query(query, trans_mat, img_maps, vox_maps, mlp_params, *, perm=(2, 1, 0
             def make():
                 try:
                     return hip.prep_percep_proj(img, packed, precision)
-                except RuntimeError as e:          # shapes / dtype pairs the projection does not take
-                    if "failed (-5)" in str(e):          # LIST_ERR_UNSUPPORTED
+                except hip.ListError as e:         # shapes / dtype pairs the projection does not take
+                    if e.code == hip.ERR_UNSUPPORTED:
                         return False
                     raise
             proj = caches.setdefault("proj:" + str(precision), _Cache()).get([img.data, packed.data], make) or None

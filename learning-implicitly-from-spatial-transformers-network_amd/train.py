@@ -122,11 +122,14 @@ def train(config):
     model = utils.get_class(config.model)(config).to(config.device)
     # Order of the reference (train.py:141-228): the optimizer covers ALL parameters (a reference-written
     # best_model_train.pt.tar holds Adam state for every one of them; frozen parameters simply never get a
-    # gradient and Adam skips them); a resume checkpoint wins over the warm start, which -- with its freezing of
-    # im_encoder / point_decoder -- only happens when there is nothing to resume from.
+    # gradient and Adam skips them); a resume checkpoint wins over the warm start.  The warm start -- with its
+    # freezing of im_encoder / point_decoder -- sits INSIDE `if config.load_pretrain:` there (train.py:152,177-228) and
+    # only runs when there is no best_model_train.pt.tar; it then writes one at epoch -1 (train.py:216-218), so a
+    # restart before the first best-save RESUMES that file and trains the encoders unfrozen.  Same here, quirk included.
     resume = config.checkpoint_dir + "best_model_train.pt.tar"
     resuming = bool(config.load_pretrain and os.path.exists(resume))
-    if config.warm_start and not resuming:
+    warm = bool(config.load_pretrain and config.warm_start and not resuming)
+    if warm:
         _warm_start(model, config)
     model = wrap_model(model, config)
 
@@ -138,6 +141,9 @@ def train(config):
     optimizer = torch.optim.Adam(model.parameters(), lr=config.lr,
                                  betas=(config.beta1, 0.999), weight_decay=config.weight_decay)
     epoch, best_train = 0, 1e3
+    if warm and ((not dist.is_initialized()) or dist.get_rank() == 0):
+        utils.save_checkpoint(-1, model, optimizer, best_train, resume)      # reference train.py:216-218
+        print("Initial checkpoint saved.")
     if resuming:
         epoch, model, optimizer, best = utils.load_checkpoint(resume, model, optimizer)
         if best is not None:

@@ -144,7 +144,7 @@ def test_backward_reduced_precision_is_within_the_stated_l2_bound(hip, golden_di
         assert rel_l2(a, g[k]) < TOL_L2[precision], (k, rel_l2(a, g[k]))
     # d fc_out.{weight,bias} do not depend on any mask: tight even here
     assert rel_max(got["d_fc_out.bias"], g["d_fc_out.bias"]) < 1e-5
-    assert rel_max(got["d_fc_out.weight"], g["d_fc_out.weight"]) < (3e-3 if precision == "fp16" else 3e-2)
+    assert rel_max(got["d_fc_out.weight"], g["d_fc_out.weight"]) < (2e-3 if precision == "fp16" else 3e-2)      # fp16: 6e-4 measured
 
 
 def test_backward_is_independent_of_point_order_and_partial_outputs(hip, golden_dir):
