@@ -333,7 +333,8 @@ def run_train_step(precision, steps, warmup, inp, hip, ev):
         sdf, ctx = hip.sdf_query(inp["query"], inp["trans_mat"], img, vox, packed, precision=precision,
                                  save_for_backward=True, clamp_hi=inp["clamp_hi"])
         if timed: ev.record(e[1])
-        out = hip.sdf_query_backward(ctx, gsdf, packed_b, stage_events=arr, img_levels_like=inp["img_maps"])
+        out = hip.sdf_query_backward(ctx, gsdf, packed_b, stage_events=arr, img_levels_like=inp["img_maps"],
+                                     want_img_map=False)      # the training step wants the encoder levels' gradients
         if timed: ev.record(e[2])
         grads = out
         return arr, e
@@ -362,7 +363,8 @@ def run_train_step(precision, steps, warmup, inp, hip, ev):
         packed_b = hip.prep_mlp_weights_bwd(inp["weights"], vox.channels, img.channels, precision)
         _, ctx = hip.sdf_query(inp["query"], inp["trans_mat"], img, vox, packed, precision=precision,
                                save_for_backward=True, clamp_hi=inp["clamp_hi"])
-        hip.sdf_query_backward(ctx, gsdf, packed_b, stage_events=arr, img_levels_like=inp["img_maps"], overlap=False)
+        hip.sdf_query_backward(ctx, gsdf, packed_b, stage_events=arr, img_levels_like=inp["img_maps"], overlap=False,
+                               want_img_map=False)
         torch.cuda.synchronize()
         for s in range(n_ev - 1):
             inl[s] += ev.elapsed_ms(ctypes.c_void_p(arr[s]), ctypes.c_void_p(arr[s + 1])) / 3

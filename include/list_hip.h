@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LIST_ABI_VERSION 5
+#define LIST_ABI_VERSION 6
 
 #define LIST_N_IMG_LEVELS 5   /* ResEncoder feature maps, network/modules.py:1067 */
 #define LIST_N_VOX_LEVELS 6   /* VoxelEncoder2 feature maps, network/modules.py:425-442 */
@@ -330,6 +330,14 @@ typedef struct ListQueryGradArgs {
                                       /*   takes them.  The adjoint resize then runs inside this call, beside the */
                                       /*   voxel scatters still in flight on the auxiliary streams (needs         */
                                       /*   grad_img_map as the intermediate).  NULL: call it yourself afterwards. */
+  int32_t grad_img_map_dtype;         /* ABI 6.  LIST_MAP_F32 (0): grad_img_map is the fp32 gradient (above).      */
+                                      /*   LIST_MAP_F16: only with grad_img_levels and fwd->precision FP16 -- the  */
+                                      /*   map gradient is an INTERMEDIATE of the adjoint resize then, kept as     */
+                                      /*   halfs at the gradient scale (grad_img_map holds B*ms*ms*img_C halfs of  */
+                                      /*   scratch afterwards, not a gradient): half the bytes between the two     */
+                                      /*   kernels (0.6 GB per step at the metric shape).  Needs the pixel-ordered */
+                                      /*   gather form (point sort on, B <= 64 images, map_size*ceil(map_size/4)   */
+                                      /*   <= 8192), else LIST_ERR_UNSUPPORTED.                                    */
 } ListQueryGradArgs;
 
 enum ListBwdStage {

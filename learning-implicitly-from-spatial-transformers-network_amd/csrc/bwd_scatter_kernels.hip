@@ -802,7 +802,10 @@ __global__ __launch_bounds__(256) void k_img_records(GatherParams g, const float
 // whose 2x2 footprint can reach the group; each contributes w(tap) * dX[row][img_off + c].
 constexpr int kImgCand = 128;
 
-template <int DXH>
+// GH (fp16 operands only): the map gradient is the intermediate of the adjoint resize in the same call -- written as
+// halfs AT the gradient scale s (the sums of a pixel's <= 4 cells of s * dX values: saturating conversion), and
+// k_img_grad_level<1> multiplies by 1 / s at its end
+template <int DXH, int GH = 0>
 __global__ __launch_bounds__(256) void k_img_grad_gather(ScatterParams sp, const ImgRec* __restrict__ recs,
                                                          const int* __restrict__ bins, int b_first, int ms,
                                                          int Ct, int img_off, float* __restrict__ out) {
@@ -872,8 +875,13 @@ __global__ __launch_bounds__(256) void k_img_grad_gather(ScatterParams sp, const
       for (int t = 0; t < 4; ++t) {
         const int X = X0 + t;
         if (X >= ms) continue;
-        float4 v = make_float4(acc[t][0] * inv_s, acc[t][1] * inv_s, acc[t][2] * inv_s, acc[t][3] * inv_s);
-        *(float4*)(out + ((int64_t)(b * ms + Y) * ms + X) * Ct + qd * 4) = v;
+        const int64_t o = ((int64_t)(b * ms + Y) * ms + X) * Ct + qd * 4;
+        if (GH) {
+          *(uint2*)((unsigned short*)out + o) = half4(make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]));
+        } else {
+          float4 v = make_float4(acc[t][0] * inv_s, acc[t][1] * inv_s, acc[t][2] * inv_s, acc[t][3] * inv_s);
+          *(float4*)(out + o) = v;
+        }
       }
     }
   }
@@ -1054,7 +1062,7 @@ __global__ __launch_bounds__(256) void k_trans_grad(ScatterParams sp, const void
 }
 
 hipError_t launch_img_grad(const ScatterParams& sp, const FeatLayout& L, const ListQueryArgs& a,
-                           const int* bins_pix, int nslots, void* recs, float* grad_img_map,
+                           const int* bins_pix, int nslots, void* recs, float* grad_img_map, int map_f16,
                            float* grad_trans_mat, void* const* stage_events, hipStream_t s) {
   (void)nslots;
   const int ms = a.map_size, Ct = L.img_C;
@@ -1068,13 +1076,19 @@ hipError_t launch_img_grad(const ScatterParams& sp, const FeatLayout& L, const L
     const int B = (int)((sp.g.p_begin + sp.g.n_valid + sp.g.N - 1) / sp.g.N);
     if (sp.g.order_img && bins_pix) {
       const dim3 grid((unsigned)(B * ms * ((ms + 3) / 4)));
-      if (sp.dx_f16)
+      if (sp.dx_f16 && map_f16)
+        hipLaunchKernelGGL((k_img_grad_gather<1, 1>), grid, dim3(256), 0, s, sp, rc, bins_pix, (int)(sp.g.p_begin / sp.g.N),
+                           ms, Ct, L.img_off, grad_img_map);
+      else if (map_f16)
+        return hipErrorInvalidValue;
+      else if (sp.dx_f16)
         hipLaunchKernelGGL(k_img_grad_gather<1>, grid, dim3(256), 0, s, sp, rc, bins_pix, (int)(sp.g.p_begin / sp.g.N),
                            ms, Ct, L.img_off, grad_img_map);
       else
         hipLaunchKernelGGL(k_img_grad_gather<0>, grid, dim3(256), 0, s, sp, rc, bins_pix, (int)(sp.g.p_begin / sp.g.N),
                            ms, Ct, L.img_off, grad_img_map);
     } else {
+      if (map_f16) return hipErrorInvalidValue;            // (list_capi.hip rejects the combination)
       hipError_t e = hipMemsetAsync(grad_img_map, 0, (size_t)B * ms * ms * Ct * sizeof(float), s);
       if (e != hipSuccess) return e;
       const dim3 grid((unsigned)((sp.g.n_valid + kGatherRows - 1) / kGatherRows));
@@ -1146,7 +1160,10 @@ constexpr int kAdjTileW = 128;             // source columns per pass of phases 
 struct AdjLevels { ListMap2D m[LIST_N_IMG_LEVELS]; int coff[LIST_N_IMG_LEVELS], maxper[LIST_N_IMG_LEVELS],
                    wg_begin[LIST_N_IMG_LEVELS], n; };
 
-__global__ __launch_bounds__(256) void k_img_grad_level(const float* __restrict__ G, int ms, int Ct, AdjLevels lv) {
+// GH: G holds halfs at the gradient scale (k_img_grad_gather<1, 1>); out = (1 / s) * adjoint
+template <int GH>
+__global__ __launch_bounds__(256) void k_img_grad_level(const float* __restrict__ G, int ms, int Ct, AdjLevels lv,
+                                                        const float* __restrict__ scale) {
   int l = 0;
 #pragma unroll
   for (int i = 1; i < LIST_N_IMG_LEVELS; ++i)
@@ -1208,12 +1225,19 @@ __global__ __launch_bounds__(256) void k_img_grad_level(const float* __restrict_
     const int oy1 = oy_range[1];
     for (int oy = oy_range[0]; oy <= oy1; ++oy) {
       const float wy = s_wy[oy];
-      const float* Gr = G + ((int64_t)(b * ms + oy) * ms) * Ct + coff + c0 + cq * 4;
+      const int64_t go = ((int64_t)(b * ms + oy) * ms) * Ct + coff + c0 + cq * 4;
 #pragma unroll
       for (int k = 0; k < kAdjCols; ++k) {
         const int ox = xl + kAdjXl * k;
         if (ox < ms) {
-          const float4 v = *(const float4*)(Gr + (int64_t)ox * Ct);
+          float4 v;
+          if (GH) {
+            const uint2 h = *(const uint2*)((const unsigned short*)G + go + (int64_t)ox * Ct);
+            v = make_float4(h2f((unsigned short)(h.x & 0xffff)), h2f((unsigned short)(h.x >> 16)),
+                            h2f((unsigned short)(h.y & 0xffff)), h2f((unsigned short)(h.y >> 16)));
+          } else {
+            v = *(const float4*)(G + go + (int64_t)ox * Ct);
+          }
           acc[k].x = fmaf(wy, v.x, acc[k].x); acc[k].y = fmaf(wy, v.y, acc[k].y);
           acc[k].z = fmaf(wy, v.z, acc[k].z); acc[k].w = fmaf(wy, v.w, acc[k].w);
         }
@@ -1236,7 +1260,7 @@ __global__ __launch_bounds__(256) void k_img_grad_level(const float* __restrict_
       const float* wx = s_wx + (x0 + xs) * maxper;
       float a = 0.f;
       for (int e = 0; e < n; ++e) a = fmaf(wx[e], R[(first + e) * kAdjCg + c], a);
-      tile[c * (kAdjTileW + 1) + xs] = a;
+      tile[c * (kAdjTileW + 1) + xs] = GH ? a * scale[1] : a;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < kAdjCg * wt; i += 256) {
@@ -1332,7 +1356,8 @@ hipError_t launch_grad_to_rows(const float* src, int64_t sb, int64_t sc, int64_t
 }
 
 hipError_t launch_img_grad_to_levels(const float* grad_img_map, int B, int map_size, int Ct,
-                                     const ListMap2D grads[LIST_N_IMG_LEVELS], hipStream_t s) {
+                                     const ListMap2D grads[LIST_N_IMG_LEVELS], hipStream_t s, int map_f16,
+                                     const float* scale) {
   if (map_size > kAdjMaxMs) return hipErrorInvalidValue;
   AdjLevels lv;
   lv.n = 0;
@@ -1359,11 +1384,16 @@ hipError_t launch_img_grad_to_levels(const float* grad_img_map, int B, int map_s
   }
   if (lv.n == 0) return hipSuccess;
   if (wgs >= 2147483647LL) return hipErrorInvalidValue;
+  if (map_f16 && !scale) return hipErrorInvalidValue;
+  const void* fn = map_f16 ? (const void*)k_img_grad_level<1> : (const void*)k_img_grad_level<0>;
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_img_grad_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(k_img_grad_level, dim3((unsigned)wgs), dim3(256), lds, s, grad_img_map, map_size, Ct, lv);
+  if (map_f16)
+    hipLaunchKernelGGL(k_img_grad_level<1>, dim3((unsigned)wgs), dim3(256), lds, s, grad_img_map, map_size, Ct, lv, scale);
+  else
+    hipLaunchKernelGGL(k_img_grad_level<0>, dim3((unsigned)wgs), dim3(256), lds, s, grad_img_map, map_size, Ct, lv, scale);
   return hipGetLastError();
 }
 

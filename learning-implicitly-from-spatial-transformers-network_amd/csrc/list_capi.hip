@@ -568,6 +568,19 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
     }
     if (ct != a->img_C) return fail(LIST_ERR_SHAPE, "grad_img_levels: channels sum to %d, the map has %d", ct, a->img_C);
   }
+  if (ga->grad_img_map_dtype != LIST_MAP_F32 && ga->grad_img_map_dtype != LIST_MAP_F16)
+    return fail(LIST_ERR_ARG, "grad_img_map_dtype=%d", ga->grad_img_map_dtype);
+  if (ga->grad_img_map_dtype == LIST_MAP_F16) {
+    // halfs at the gradient scale between the map-side gather and the adjoint resize: an intermediate, not an output
+    if (!ga->grad_img_levels || !ga->grad_img_map)
+      return fail(LIST_ERR_ARG, "grad_img_map_dtype = F16 is the intermediate of grad_img_levels: pass both");
+    if (a->precision != LIST_PREC_FP16)
+      return fail(LIST_ERR_UNSUPPORTED, "grad_img_map_dtype = F16 needs fp16 operands (fwd->precision FP16)");
+    if (a->no_sort || a->percep_feat || a->B > kSortImages || a->map_size * ((a->map_size + 3) / 4) > kSortPixCells)
+      return fail(LIST_ERR_UNSUPPORTED, "grad_img_map_dtype = F16 needs the pixel-ordered gather form (point sort on, "
+                                        "B <= %d, map_size * ceil(map_size / 4) <= %d)", kSortImages, kSortPixCells);
+    if (a->img_C % 4) return fail(LIST_ERR_UNSUPPORTED, "grad_img_map_dtype = F16 needs img_C %% 4 == 0");
+  }
   if (a->percep_feat && (ga->grad_img_map || ga->grad_trans_mat))
     return fail(LIST_ERR_ARG, "with percep_feat the perceptual gradient is grad_percep_feat, not grad_img_map/grad_trans_mat");
   if (!a->percep_feat && ga->grad_percep_feat)
@@ -810,11 +823,12 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   const int nslots = a->B < kSortImages ? a->B : kSortImages;
   const int* bins_pix = pix ? (const int*)(fw + ws.bins) + (size_t)nslots * kSortCells : nullptr;
   if (pix && a->B > kSortImages) { sp.g.order_img = nullptr; sp.g.row_of = nullptr; bins_pix = nullptr; }
-  LIST_TRY(launch_img_grad(sp, L, *a, bins_pix, nslots, bwp + bw.recs, ga->grad_img_map, ga->grad_trans_mat,
+  const int map_f16 = ga->grad_img_map_dtype == LIST_MAP_F16 ? 1 : 0;
+  LIST_TRY(launch_img_grad(sp, L, *a, bins_pix, nslots, bwp + bw.recs, ga->grad_img_map, map_f16, ga->grad_trans_mat,
                            ga->stage_events, s), "image gradient launch");
   if (ga->grad_img_levels)
-    LIST_TRY(launch_img_grad_to_levels(ga->grad_img_map, a->B, a->map_size, L.img_C, ga->grad_img_levels, s),
-             "img_grad_to_levels launch");
+    LIST_TRY(launch_img_grad_to_levels(ga->grad_img_map, a->B, a->map_size, L.img_C, ga->grad_img_levels, s, map_f16,
+                                       scale), "img_grad_to_levels launch");
   LIST_TRY(hand_over(s_direct, s), "stream join");
   LIST_TRY(hand_over(s_window, s), "stream join");
 #undef LIST_TRY
@@ -863,7 +877,7 @@ int list_percep_pool_bwd(const ListPoolGradArgs* ga, void* stream) {
   sp.g.perm0 = 0; sp.g.perm1 = 1; sp.g.perm2 = 2; sp.g.scale = 1.f;
   sp.g.N = a->N; sp.g.p_begin = 0; sp.g.n_valid = (int)P; sp.g.rows = (int)rows; sp.g.Kp = a->img_C;
   sp.dx = dx; sp.dx_f16 = 0; sp.scale = scale;
-  e = launch_img_grad(sp, L, q, nullptr, 0, recs, ga->grad_img_map, ga->grad_trans_mat, nullptr, s);
+  e = launch_img_grad(sp, L, q, nullptr, 0, recs, ga->grad_img_map, 0, ga->grad_trans_mat, nullptr, s);
   if (e != hipSuccess) return hip_fail(e, "percep_pool_bwd launch");
   return LIST_OK;
 }

@@ -472,14 +472,16 @@ struct ScatterStreams { hipStream_t gather, direct, window; };
 hipError_t launch_scatter_vox(const ScatterParams& sp, const FeatLayout& L, const ListQueryArgs& a,
                               const ListVoxLevel grad_vox[LIST_N_VOX_LEVELS], const VoxGatherBuffers& vb,
                               const ScatterStreams& st);
+// map_f16: grad_img_map receives halfs at the gradient scale (the intermediate of the adjoint resize, fp16 operands)
 hipError_t launch_img_grad(const ScatterParams& sp, const FeatLayout& L, const ListQueryArgs& a,
-                           const int* bins_pix, int nslots, void* recs, float* grad_img_map,
+                           const int* bins_pix, int nslots, void* recs, float* grad_img_map, int map_f16,
                            float* grad_trans_mat, void* const* stage_events, hipStream_t s);
 hipError_t launch_rows_to_grad(const ScatterParams& sp, int img_off, int C, int B, int* row_of_scratch, float* out,
                                int64_t sb, int64_t sc, int64_t sn, hipStream_t s);
 hipError_t launch_grad_to_rows(const float* src, int64_t sb, int64_t sc, int64_t sn, int B, int N, int C, float* dx,
                                float* scale, hipStream_t s);
 hipError_t launch_img_grad_to_levels(const float* grad_img_map, int B, int map_size, int Ct,
-                                     const ListMap2D grads[LIST_N_IMG_LEVELS], hipStream_t s);
+                                     const ListMap2D grads[LIST_N_IMG_LEVELS], hipStream_t s, int map_f16 = 0,
+                                     const float* scale = nullptr);
 
 }  // namespace list

@@ -110,7 +110,8 @@ class _SdfQueryHipFn(torch.autograd.Function):
         for n0, n1, qctx in ctx.pieces:
             out = hip.sdf_query_backward(qctx, grad_out[:, n0:n1], ctx.state["packed_bwd"](), want_mlp=want_mlp,
                                          want_img=(want_lead if percep else want_img), want_vox=want_vox,
-                                         want_trans=(want_lead and not percep), img_levels_like=like)
+                                         want_trans=(want_lead and not percep), img_levels_like=like,
+                                         want_img_map=like is None)       # one piece: only the levels are wanted
             if percep and want_lead:
                 lead_parts.append(out.pop("percep_feat"))
             if total is None:

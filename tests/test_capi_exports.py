@@ -36,9 +36,9 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_error_string_without_gpu():
     from list_amd import hip
     lib = hip.load()
-    assert lib.list_abi_version() == 5
+    assert lib.list_abi_version() == 6
     text = open(os.path.join(ROOT, "include", "list_hip.h")).read()
-    assert "#define LIST_ABI_VERSION 5" in text
+    assert "#define LIST_ABI_VERSION 6" in text
     # argument validation happens before any HIP call: a NULL args struct is rejected cleanly
     assert lib.list_sdf_query_fwd(None, None) == -1
     assert b"NULL" in lib.list_last_error()

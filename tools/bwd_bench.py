@@ -40,7 +40,8 @@ for it in range(steps + 2):
     in_call = os.environ.get("LIST_BWD_LEVELS_IN_CALL", "1") == "1"
     out = hip.sdf_query_backward(ctx, gsdf, packed_b, stage_events=arr,
                                  overlap=os.environ.get("LIST_BWD_OVERLAP", "1") == "1",
-                                 img_levels_like=inp["img_maps"] if in_call else None)
+                                 img_levels_like=inp["img_maps"] if in_call else None,
+                                 want_img_map=os.environ.get("LIST_BWD_WANT_IMG_MAP", "0") == "1")
     ev.record(e[3])
     lv = out["img_levels"] if in_call else hip.img_map_grad_to_levels(out["img_map"], inp["img_maps"])
     e4 = ev.create(); ev.record(e4)
