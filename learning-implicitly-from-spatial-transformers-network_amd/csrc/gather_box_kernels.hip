@@ -30,7 +30,6 @@
 #include "point_math.h"
 
 namespace list {
-namespace {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -460,8 +459,6 @@ __global__ __launch_bounds__(256) void k_gather_vox_box(GatherParams g, ListVoxL
   }
 #endif
 }
-
-}  // namespace
 
 // near level with fp16 maps and an fp16 feature matrix; false: not taken (the caller falls back to k_gather_vox_near)
 bool gather_box_eligible(const GatherParams& g, const ListVoxLevel& lv, int col_off) {
