@@ -156,7 +156,7 @@ struct Run { int first, count, direct; int ox, oy, oz, nx, ny, nz, b; };
 // read-add-writes with the per-axis 4-slot weight vectors of the centre / minus / plus samples:
 //   X[k] = g0 wcx[k] + g1 wmx[k] + g2 wpx[k],  Y[k] = g3 wmy[k] + g4 wpy[k],  Z[k] = g5 wmz[k] + g6 wpz[k]
 //   dV[kx][ky][kz] = X[kx] wcy[ky] wcz[kz] + wcx[kx] Y[ky] wcz[kz] + wcx[kx] wcy[ky] Z[kz]
-struct NearRec { int o[32]; float wx[3][4], wy[3][4], wz[3][4]; };
+struct NearRec { int o[32]; float wx[3][4], wy[3][4], wz[3][4]; int cell; int pad_[3]; };
 
 __device__ __forceinline__ void slot_weights(const Axis& a, int cbase, float (&w)[4], bool (&used)[4]) {
   const int k0 = a.i0 - cbase;            // 0, 1 or 2
@@ -168,38 +168,51 @@ __device__ __forceinline__ void slot_weights(const Axis& a, int cbase, float (&w
   }
 }
 
-__device__ __forceinline__ void build_near(const Pt& p, int W, int H, int D, const Run& r, int C, NearRec& n) {
+// The 32 window offsets are a function of the point's BASE CELL and the run's box alone: a slot inside the box gets its
+// voxel, whether this point's samples use it or not (an unused slot receives G = 0 exactly), a slot outside the box
+// (no point of the run uses it: the box covers every used tap) goes to the dummy cell.  Consecutive points of one base
+// cell -- ~4 at 16^3, tens at 8^3 in Morton order -- therefore share their offsets, and the kernel sums their 32
+// contributions in registers and touches the window once per cell group (round 3: the per-point read-add-write chain
+// was 41 - 47 % of the kernel, profiles/r03_window_adjoint_ablation.txt).
+// Built by 16 threads per point (sub = 0..15): every thread derives the nine per-axis records itself (they are cheap)
+// and writes two offsets and, for sub < 9, one weight row.
+__device__ __forceinline__ void build_near(const Pt& p, int W, int H, int D, const Run& r, int C, NearRec& n, int sub) {
   const float pc[3] = {p.x, p.y, p.z};
   const int S[3] = {W, H, D};
   int base[3];
-  bool used[3][4];
 #pragma unroll
   for (int ax = 0; ax < 3; ++ax) {
     const Axis c = axis_setup(pc[ax], S[ax]), m = axis_setup(pc[ax] - kDisp, S[ax]), q = axis_setup(pc[ax] + kDisp, S[ax]);
     base[ax] = c.i0 - 1;
+    bool used[4] = {false, false, false, false};
+    float w[3][4];
+    slot_weights(c, base[ax], w[0], used);
+    slot_weights(m, base[ax], w[1], used);
+    slot_weights(q, base[ax], w[2], used);
+    float(*dst)[4] = ax == 0 ? n.wx : (ax == 1 ? n.wy : n.wz);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) used[ax][k] = false;
-    float(*w)[4] = ax == 0 ? n.wx : (ax == 1 ? n.wy : n.wz);
-    slot_weights(c, base[ax], w[0], used[ax]);
-    slot_weights(m, base[ax], w[1], used[ax]);
-    slot_weights(q, base[ax], w[2], used[ax]);
+    for (int v = 0; v < 3; ++v)
+      if (sub == ax * 3 + v) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[v][k] = p.valid ? w[v][k] : 0.f;
+      }
   }
   const int vol = r.nx * r.ny * r.nz;
   auto cell = [&](int kx, int ky, int kz) -> int {
-    if (!p.valid || !used[0][kx] || !used[1][ky] || !used[2][kz]) return vol * C;      // dummy cell
-    return (((base[2] + kz - r.oz) * r.ny + (base[1] + ky - r.oy)) * r.nx + (base[0] + kx - r.ox)) * C;
+    const int ix = base[0] + kx - r.ox, iy = base[1] + ky - r.oy, iz = base[2] + kz - r.oz;
+    if (!p.valid || ix < 0 || ix >= r.nx || iy < 0 || iy >= r.ny || iz < 0 || iz >= r.nz) return vol * C;   // dummy cell
+    return ((iz * r.ny + iy) * r.nx + ix) * C;
   };
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) n.o[k * 4 + q] = cell(k, 1 + (q & 1), 1 + (q >> 1));
-#pragma unroll
-  for (int e = 0; e < 2; ++e)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      n.o[16 + e * 4 + q] = cell(1 + (q & 1), e ? 3 : 0, 1 + (q >> 1));
-      n.o[24 + e * 4 + q] = cell(1 + (q & 1), 1 + (q >> 1), e ? 3 : 0);
-    }
+  for (int e = 0; e < 2; ++e) {
+    const int s = 2 * sub + e;                       // window slot 0..31 (order of the forward's shared-tap kernel)
+    int kx, ky, kz;
+    if (s < 16) { kx = s >> 2; ky = 1 + (s & 1); kz = 1 + ((s >> 1) & 1); }
+    else if (s < 24) { kx = 1 + (s & 1); ky = (s & 4) ? 3 : 0; kz = 1 + ((s >> 1) & 1); }
+    else { kx = 1 + (s & 1); ky = 1 + ((s >> 1) & 1); kz = (s & 4) ? 3 : 0; }
+    n.o[s] = cell(kx, ky, kz);
+  }
+  if (sub == 15) n.cell = p.valid ? (base[0] + 1) | ((base[1] + 1) << 10) | ((base[2] + 1) << 20) : -1;
 }
 
 // kWinFloats: 18432 (72 KB, two workgroups per CU) for the 16^3 level, whose runs need ~100-voxel boxes;
@@ -251,6 +264,7 @@ __global__ __launch_bounds__((C >= 128 ? C : 128)) void k_scatter_vox_win(Scatte
   __shared__ Run runs[kNSub];
   __shared__ int n_runs;
   __shared__ NearRec nrec[kSubPts];
+  __shared__ int grp_off[T / 64][32];
   __shared__ float win[kWinFloats];
   const int tid = threadIdx.x;
   const int c = tid % C, k = tid / C;
@@ -303,7 +317,12 @@ __global__ __launch_bounds__((C >= 128 ? C : 128)) void k_scatter_vox_win(Scatte
   const int nr = n_runs;
 #pragma unroll 1
   for (int ri = 0; ri < nr; ++ri) {
-    const Run r = runs[ri];
+    Run r = runs[ri];
+    // (uniform: the window offsets of a cell group are then scalar arithmetic, not 32 more registers)
+    r.first = __builtin_amdgcn_readfirstlane(r.first); r.count = __builtin_amdgcn_readfirstlane(r.count);
+    r.direct = __builtin_amdgcn_readfirstlane(r.direct); r.b = __builtin_amdgcn_readfirstlane(r.b);
+    r.ox = __builtin_amdgcn_readfirstlane(r.ox); r.oy = __builtin_amdgcn_readfirstlane(r.oy); r.oz = __builtin_amdgcn_readfirstlane(r.oz);
+    r.nx = __builtin_amdgcn_readfirstlane(r.nx); r.ny = __builtin_amdgcn_readfirstlane(r.ny); r.nz = __builtin_amdgcn_readfirstlane(r.nz);
     if (r.direct) {
       if (DXH && img16) scatter_direct_h2<C, T>(sp, gv, col_off, pts, r.first, r.first + r.count, row0, img16);
       else scatter_direct<C, DXH, T>(sp, gv, col_off, pts, r.first, r.first + r.count, row0, inv_s);
@@ -312,10 +331,37 @@ __global__ __launch_bounds__((C >= 128 ? C : 128)) void k_scatter_vox_win(Scatte
     const int nx = r.nx, ny = r.ny, vol = r.nx * r.ny * r.nz;
     float* mine = win + (k * (vol + 1)) * C + c;     // my column of my copy
     for (int v = 0; v <= vol; ++v) mine[v * C] = 0.f;
+    // contributions of the current base-cell group: summed in registers, added to the window once per group
+    int cur_cell = -2;
+    float Gacc[32];
+    // the group's 32 window offsets: copied from its first point's record into a per-wave LDS row when the group
+    // opens (the record itself is overwritten by the next chunk; DS operations of one wave execute in order)
+    int* gro = grp_off[tid >> 6];
+    auto add_group = [&]() {
+#ifdef LIST_WIN_NO_RMW             // ablation (wrong results): the read-add-writes of a group collapse into one
+      float gs = 0.f;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) gs += Gacc[q];
+      mine[0] += gs;
+#else
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {                  // two batches of 16 (addresses are distinct within the 32, or the dummy)
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = mine[gro[16 * h + q]];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) mine[gro[16 * h + q]] = v[q] + Gacc[16 * h + q];
+      }
+#endif
+    };
 #pragma unroll 1
     for (int ch = 0; ch < r.count; ch += kSubPts) {
       __syncthreads();                               // previous chunk's records are consumed
-      if (tid < kSubPts) build_near(pts[r.first + ch + tid], W, H, D, r, C, nrec[tid]);
+#ifndef LIST_WIN_NO_RECORDS        // ablation (wrong results): the per-point records are built once per workgroup only
+      if (tid < kSubPts * 16) build_near(pts[r.first + ch + (tid >> 4)], W, H, D, r, C, nrec[tid >> 4], tid & 15);
+#else
+      if (tid < kSubPts * 16 && ri == 0 && ch == 0) build_near(pts[r.first + ch + (tid >> 4)], W, H, D, r, C, nrec[tid >> 4], tid & 15);
+#endif
       // my points of the chunk: every dX value is requested before the first use
       float gval[MYP][LIST_N_STENCIL];
 #pragma unroll
@@ -336,31 +382,37 @@ __global__ __launch_bounds__((C >= 128 ? C : 128)) void k_scatter_vox_win(Scatte
           Y[q] = fmaf(g[4], n.wy[2][q], g[3] * n.wy[1][q]);
           Z[q] = fmaf(g[6], n.wz[2][q], g[5] * n.wz[1][q]);
         }
-        float G[32];
+        const int cell = __builtin_amdgcn_readfirstlane(n.cell);          // (the same point for the whole wave)
+        if (cell != cur_cell) {
+          if (cur_cell != -2) add_group();
+          cur_cell = cell;
+          if ((tid & 63) < 32) gro[tid & 31] = n.o[tid & 31];
+#pragma unroll
+          for (int q = 0; q < 32; ++q) Gacc[q] = 0.f;
+        }
 #pragma unroll
         for (int kx = 0; kx < 4; ++kx)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int ky = 1 + (q & 1), kz = 1 + (q >> 1);
-            G[kx * 4 + q] = fmaf(X[kx], n.wy[0][ky] * n.wz[0][kz],
-                                 n.wx[0][kx] * fmaf(Y[ky], n.wz[0][kz], n.wy[0][ky] * Z[kz]));
+            Gacc[kx * 4 + q] += fmaf(X[kx], n.wy[0][ky] * n.wz[0][kz],
+                                     n.wx[0][kx] * fmaf(Y[ky], n.wz[0][kz], n.wy[0][ky] * Z[kz]));
           }
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int ka = 1 + (q & 1), kb = 1 + (q >> 1), ke = e ? 3 : 0;
-            G[16 + e * 4 + q] = n.wx[0][ka] * Y[ke] * n.wz[0][kb];
-            G[24 + e * 4 + q] = n.wx[0][ka] * n.wy[0][kb] * Z[ke];
+            Gacc[16 + e * 4 + q] += n.wx[0][ka] * Y[ke] * n.wz[0][kb];
+            Gacc[24 + e * 4 + q] += n.wx[0][ka] * n.wy[0][kb] * Z[ke];
           }
-        float v[32];
-#pragma unroll
-        for (int q = 0; q < 32; ++q) v[q] = mine[n.o[q]];
-#pragma unroll
-        for (int q = 0; q < 32; ++q) mine[n.o[q]] = v[q] + G[q];
       }
     }
+    if (cur_cell != -2) add_group();
     __syncthreads();
+#ifdef LIST_WIN_NO_FLUSH           // ablation (wrong results): the window is never flushed
+    if (sp.g.Kp < 0)
+#endif
     if (DXH && img16) {
       _Float16* base16 = img16 + (int64_t)r.b * gv.image_stride;
       for (int i = tid; i < vol * (C / 2); i += T) {

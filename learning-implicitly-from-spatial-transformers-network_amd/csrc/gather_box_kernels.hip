@@ -42,10 +42,18 @@ constexpr int kBoxMaxKeys = 512;                             // window keys a ru
 #define LIST_BOX_NB 2                                        // tiles per turn of a wave
 #endif
 #ifndef LIST_BOX_ROWS_BIG
-#define LIST_BOX_ROWS_BIG 256                                // LDS box rows, levels wider than 8 voxels
+#ifdef LIST_BOX_XPOSE
+#define LIST_BOX_ROWS_BIG 224                                // LDS box rows, levels wider than 8 voxels (2 workgroups per CU)
+#else
+#define LIST_BOX_ROWS_BIG 256
+#endif
 #endif
 #ifndef LIST_BOX_ROWS_SMALL
+#ifdef LIST_BOX_XPOSE
+#define LIST_BOX_ROWS_SMALL 120                              // (3 workgroups per CU)
+#else
 #define LIST_BOX_ROWS_SMALL 128
+#endif
 #endif
 
 struct AxisW { int i0; float w0, w1; };                     // base index; w1 = 0 where the +1 tap is skipped
@@ -82,7 +90,12 @@ template <int C, int MAXROWS> struct BoxLds {
   static constexpr int sorted = tileinfo + kBoxSamples * 4;              // short [448]: sample ids in key order
   static constexpr int pbox = sorted + kBoxSamples * 2;                  // int [64][4]: tap range per axis, image
   static constexpr int misc = pbox + kBoxPts * 16;                       // int [8]: tile count
+#ifdef LIST_BOX_XPOSE
+  static constexpr int xpose = misc + 64;                                // 4 waves x [8 samples][256 B]: store staging
+  static constexpr int total = xpose + 4 * 8 * kRowBytes;
+#else
   static constexpr int total = misc + 64;
+#endif
 };
 
 __device__ __forceinline__ s16x4 tr_read16(const char* l) {
@@ -420,6 +433,36 @@ __global__ __launch_bounds__(256) void k_gather_vox_box(GatherParams g, ListVoxL
         // D^T: column = sample (lane & 15), rows 4 q + reg of tile t = channels 32 (t >> 1) + 8 q + 4 (t & 1) + reg.
         // Plain stores: the four lanes of a sample cover 64 B per instruction and the partial lines merge in L2
         // (non-temporal stores of such pieces took the kernel from 0.085 to 0.30 ms)
+#ifdef LIST_BOX_XPOSE
+        {
+          // whole rows per store instruction: the tile turns through a wave-private LDS image, 8 samples at a time
+          // ([sample][16-B chunk ^ sample]: conflict-free both ways; DS operations of one wave execute in order), then
+          // every 16 lanes hold one sample's 256 B -> non-temporal stores of full rows like the scalar kernels'
+          typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+          char* tw = smem + L::xpose + wave * (8 * RB);
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            if ((col >> 3) == hh) {
+#pragma unroll
+              for (int u = 0; u < NT / 2; ++u) {
+                const uint2 lo = half4_inrange(make_float4(acc[2 * u][0], acc[2 * u][1], acc[2 * u][2], acc[2 * u][3]));
+                const uint2 hi = half4_inrange(make_float4(acc[2 * u + 1][0], acc[2 * u + 1][1], acc[2 * u + 1][2], acc[2 * u + 1][3]));
+                *(uint4*)(tw + (col & 7) * RB + (((4 * u + q) ^ (col & 7)) << 4)) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+              }
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+              const int r8 = 4 * k2 + (lane >> 4), chunk = lane & 15;
+              const uint4 v = *(const uint4*)(tw + r8 * RB + ((chunk ^ r8) << 4));
+              const int sd = __shfl(sid[b], 8 * hh + r8);
+              if (sd >= 0) {
+                unsigned short* dst = xh + (row0 + (sd >> 3)) * g.Kp + col_off + (sd & 7) * C + 8 * chunk;
+                __builtin_nontemporal_store((u32x4){v.x, v.y, v.z, v.w}, (u32x4*)dst);
+              }
+            }
+          }
+        }
+#else
         if (sid[b] >= 0) {
           const int pt = sid[b] >> 3, j = sid[b] & 7;
           unsigned short* dst = xh + (row0 + pt) * g.Kp + col_off + j * C + 8 * q;
@@ -442,6 +485,7 @@ __global__ __launch_bounds__(256) void k_gather_vox_box(GatherParams g, ListVoxL
 #endif
           }
         }
+#endif
       }
     }
     first += count;
