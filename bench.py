@@ -523,7 +523,9 @@ def main():
     ap.add_argument("--global-batch", type=int, default=64)
     ap.add_argument("--sustained-steps", type=int, default=1000,
                     help="length of the sustained leg behind the timed region (0: none); reported, never the headline")
-    ap.add_argument("--cpu-sample-images", type=int, default=2)
+    ap.add_argument("--cpu-sample-images", type=int, default=8,
+                    help="images of the CPU baseline sample (default: the whole batch of the metric workload -- the 2-image sample "
+                         "of rounds 1-2 read 1.8x low, profiles/r03_cpu_baseline_8_images.json)")
     ap.add_argument("--cpu-sample-points", type=int, default=50000,
                     help="points per image of the CPU baseline sample (bounds the 256^3 grid workload)")
     args = ap.parse_args()
