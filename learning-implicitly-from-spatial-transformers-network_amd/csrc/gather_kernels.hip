@@ -105,7 +105,7 @@ __device__ __forceinline__ void store_feats(unsigned short* __restrict__ xh, uns
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     const uint2 lo = half4_inrange(valid ? make_float4(a[0], a[1], a[2], a[3]) : make_float4(0.f, 0.f, 0.f, 0.f));
     const uint2 hi = half4_inrange(valid ? make_float4(a[4], a[5], a[6], a[7]) : make_float4(0.f, 0.f, 0.f, 0.f));
-    __builtin_nontemporal_store((u32x4){lo.x, lo.y, hi.x, hi.y}, (u32x4*)(xh + off));
+    x_store<true>((u32x4){lo.x, lo.y, hi.x, hi.y}, (u32x4*)(xh + off));
     return;
   }
 #pragma unroll

@@ -36,6 +36,24 @@ inline int any_order() {
 #define LIST_LAUNCH(kernel, grid, block, lds, s, order, ...) \
   hipExtLaunchKernelGGL(kernel, grid, block, lds, s, nullptr, nullptr, (order), __VA_ARGS__)
 
+// X stores of the gathers.  Split formats (hi / lo halfs, 4 B per feature): non-temporal -- X is written once and next
+// read by fc_0, and should not evict the map lines the gathers re-read from L2 (round 1: 2-D gather 0.30 -> 0.25 ms).
+// fp16 X (round 3): PLAIN stores -- the pieces a gather writes (32 B ... 256 B per sample) merge in L2 into whole lines
+// before they leave; all gathers plain against all non-temporal on one device, four interleaved runs: gather group
+// 0.866 -> 0.841 ms, step 2.110 -> 2.085 ms (no difference in bf16x3, whose pieces are twice as long).
+// -DLIST_X_NT_STORES / -DLIST_X_PLAIN_STORES force one policy for A/B runs.
+template <bool FP16, typename V>
+__device__ __forceinline__ void x_store(const V& v, V* p) {
+#if defined(LIST_X_PLAIN_STORES)
+  *p = v;
+#elif defined(LIST_X_NT_STORES)
+  __builtin_nontemporal_store(v, p);
+#else
+  if (FP16) *p = v;
+  else __builtin_nontemporal_store(v, p);
+#endif
+}
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -126,18 +144,17 @@ template <int FMT>
 __device__ __forceinline__ void store_feat4(unsigned short* x_hi, unsigned short* x_lo, int64_t off,
                                             const float4& v) {
   typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-  // X is written once and next read by the MLP kernel: non-temporal stores keep it from evicting
-  // the map lines the gathers are re-reading from L2 (measured: 2-D gather 0.30 -> 0.25 ms)
+  // (store policy: x_store above)
   if (FMT == FMT_FP16) {
     const uint2 h = half4(v);
-    __builtin_nontemporal_store((u32x2){h.x, h.y}, (u32x2*)(x_hi + off));
+    x_store<true>((u32x2){h.x, h.y}, (u32x2*)(x_hi + off));
   } else {
     uint2 hi, lo;
     split4(v, hi, lo);
     (void)x_lo;
     unsigned short* d = x_hi + xi_off(off);
-    __builtin_nontemporal_store((u32x2){hi.x, hi.y}, (u32x2*)d);
-    __builtin_nontemporal_store((u32x2){lo.x, lo.y}, (u32x2*)(d + kXiLo));
+    x_store<false>((u32x2){hi.x, hi.y}, (u32x2*)d);
+    x_store<false>((u32x2){lo.x, lo.y}, (u32x2*)(d + kXiLo));
   }
 }
 template <int FMT>
