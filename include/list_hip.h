@@ -194,6 +194,12 @@ typedef struct ListQueryArgs {
                                         /*   that block; img_map is still required (its descriptor   */
                                         /*   fields are checked), percep_feat must be NULL, and the  */
                                         /*   call cannot be followed by list_sdf_query_bwd           */
+  int32_t no_activations;               /* ABI 6.  1: nothing of this forward is kept for          */
+                                        /*   list_sdf_query_bwd (inference).  fc_1, fc_2 and fc_out  */
+                                        /*   then run as ONE kernel that keeps H2 in registers (fp16 */
+                                        /*   operands, H2 = H3 = 256; other cases: no effect).  Same */
+                                        /*   values up to the order of the fp32 sums.  0 (default):  */
+                                        /*   H1 and H2 are left in the workspace for the backward.   */
 } ListQueryArgs;
 
 /* Boundaries recorded into ListQueryArgs.stage_events: one hipEvent after each kernel (group) of a

@@ -879,6 +879,181 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt16(GemmParams p) {
   gemm_epilogue16<EPI, FP16>(p, acc, smem, m0, n0, wm, wn, wave, lane);
 }
 
+// ---- fc_1 + fc_2 + fc_out in ONE launch (fp16 operands, inference: no activation is kept) --------------------------
+// network/modules.py:277-281 for one 256-row tile per workgroup.  H2 = relu(fc_1) never leaves the registers: the
+// products are taken TRANSPOSED (D^T[n][row] = sum_k W[n][k] H[row][k]: the weight fragment is the MFMA's A operand,
+// the activation fragment its B operand), every wave owns 32 rows and ALL 256 columns (8 x 1 waves: 16 x 2 tiles of
+// 16 x 16).  Which fc_1 column sits in which MFMA row is free -- it is only the row address of the W1 fragment -- and is
+// chosen so that row m of column tiles 2 ks / 2 ks + 1 is column 32 ks + 8 (m >> 2) + (m & 3) (+ 4): a lane's accumulators
+// of the two tiles (four columns each, bias + ReLU + fp16 in place) are then columns 32 ks + 8 q .. + 7 (q = lane >> 4),
+// i.e. exactly its B fragment of fc_2's k-step ks in natural k order.  Same products, same k order, same summation tree
+// in the fc_out epilogue as the two-launch path: bit-identical to it (asserted: a training forward, which keeps H1 / H2
+// for the backward and takes the two launches, equals the inference forward bit for bit, tests/test_threads_gpu.py).
+// LDS: fc_1 streams H1 / W1 through the two 64-KB stages of the plain loop; W2 (128 KB) is resident for fc_2 -- its
+// first K-tile prefetched into the last 32 KB at the start, the other three into the dead stages behind fc_1's last
+// K-tile, waited for tile by tile (counted vmcnt).  What it removes against the two launches: H2's round trip (82 MB
+// written and read per 160 k points), fc_1's LDS-staged store epilogue, fc_2's operand prologue, a queue boundary.
+struct TailParams {
+  GemmParams fc1;                   // a_hi = H1 [M][K], w_hi = W1 [256][K], bias = b1, K = H1 width, M
+  const char* w2; const float* b2;  // [256][256] fp16, [256]
+  const float* w3; const float* b3; float* sdf; const int* order; int n_valid;
+};
+constexpr int kTailLds = 163840;
+
+__global__ __launch_bounds__(512, 2) void k_mlp_tail_f16(TailParams tp) {
+  using P = Pipe<1>;
+  __shared__ __attribute__((aligned(16))) char smem[kTailLds];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m0 = xcd_contiguous_block(blockIdx.x, gridDim.x) * BM;
+  const int col = lane & 15, q = lane >> 4;
+  const int fswz = P::swz(col);                         // rows of a fragment are (multiple of 16) + col
+  const GemmParams& p = tp.fc1;
+
+  // W2 K-tile kt: [256 n][64 k] as 128-B rows, 16-B chunks XOR-swizzled like every operand image (on the source address)
+  auto w2_base = [&](int kt) -> char* { return smem + (kt == 0 ? 131072 : (kt - 1) * 32768); };
+  auto stage_w2 = [&](int kt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int piece = 4 * wave + r;
+      const int row = piece * 8 + lane / 8;
+      const int chunk = (lane % 8) ^ P::swz(row);
+      glds16(tp.w2 + (int64_t)row * 512 + kt * 128 + chunk * 16, w2_base(kt) + piece * 1024);
+    }
+  };
+  stage_w2(0);
+
+  // ---- fc_1: plain 2-stage loop (as k_gemm_nt16), 8 x 1 waves, transposed products
+  f32x4v acc[16][2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+  const int h_row_off = (wave * 32 + col) * P::kRowBytes;
+  // fc_1 column of MFMA row `col` in an even / odd column tile of a pair (see the header), and its chunk swizzle
+  const int wrow_e = 8 * (col >> 2) + (col & 3), wrow_o = wrow_e + 4;
+  const int wswz_e = P::swz(wrow_e), wswz_o = P::swz(wrow_o);
+  const int nk = p.K / P::BK;
+  stage_tiles<1>(p, smem, m0, 0, 0, wave, lane);
+  for (int t = 0; t < nk; ++t) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (t + 1 < nk) stage_tiles<1>(p, smem + ((t + 1) & 1) * P::kStageBytes, m0, 0, (t + 1) * P::kRowBytes, wave, lane);
+    const char* cur = smem + (t & 1) * P::kStageBytes;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int coff = ((4 * s2 + q) ^ fswz) << 4;
+      bf16x8 hf[2];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) hf[rt] = *(const bf16x8*)(cur + h_row_off + rt * 16 * P::kRowBytes + coff);
+#pragma unroll
+      for (int nt = 0; nt < 16; ++nt) {
+        // (32 (nt >> 1) is a multiple of 16: it does not change the swizzle of the row)
+        const int wrow = 32 * (nt >> 1) + ((nt & 1) ? wrow_o : wrow_e);
+        const bf16x8 wf = *(const bf16x8*)(cur + P::kWOff + wrow * P::kRowBytes + (((4 * s2 + q) ^ ((nt & 1) ? wswz_o : wswz_e)) << 4));
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) acc[nt][rt] = mfma16<1>(wf, hf[rt], acc[nt][rt]);
+      }
+    }
+  }
+  // bias of fc_1 for this lane's columns (32 (nt >> 1) + 8 q + 4 (nt & 1) + e), requested before the W2 stream
+  float4 b1v[16];
+#pragma unroll
+  for (int nt = 0; nt < 16; ++nt) b1v[nt] = *(const float4*)(p.bias + 32 * (nt >> 1) + 8 * q + 4 * (nt & 1));
+  __syncthreads();                                       // every wave is done with fc_1's stages (and b1 has landed)
+  stage_w2(1); stage_w2(2); stage_w2(3);
+  // H2 = relu(fc_1 + b1) in fp16 (the rounding of the two-launch path: saturating RNE), packed as fc_2's B fragments
+  uint2 h2[16][2];
+#pragma unroll
+  for (int nt = 0; nt < 16; ++nt) {
+    const float bb[4] = {b1v[nt].x, b1v[nt].y, b1v[nt].z, b1v[nt].w};
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = relu_nan(acc[nt][rt][e] + bb[e]);
+      h2[nt][rt] = make_uint2(f2h2(v[0], v[1]), f2h2(v[2], v[3]));
+    }
+  }
+  // ---- fc_2: K = 256 = 8 k-steps; accumulators D2^T[n2][row]
+  f32x4v acc2[16][2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc2[i][j][e] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    if (ks == 2) { wait_vmcnt<8>(); __builtin_amdgcn_s_barrier(); }      // W2 tile 1 has landed for everybody
+    if (ks == 4) { wait_vmcnt<4>(); __builtin_amdgcn_s_barrier(); }
+    if (ks == 6) { wait_vmcnt<0>(); __builtin_amdgcn_s_barrier(); }
+    const char* wt = w2_base(ks >> 1);
+    const int coff = ((4 * (ks & 1) + q) ^ fswz) << 4;
+    bf16x8 hb[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+      hb[rt] = __builtin_bit_cast(bf16x8, make_uint4(h2[2 * ks][rt].x, h2[2 * ks][rt].y, h2[2 * ks + 1][rt].x, h2[2 * ks + 1][rt].y));
+#pragma unroll
+    for (int mt = 0; mt < 16; ++mt) {
+      const bf16x8 wf = *(const bf16x8*)(wt + (mt * 16 + col) * P::kRowBytes + coff);
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) acc2[mt][rt] = mfma16<1>(wf, hb[rt], acc2[mt][rt]);
+    }
+  }
+  // ---- fc_out: sdf[row] = b3 + sum_n2 relu(fc_2 + b2)[n2] w3[n2] in the summation order of gemm_epilogue16's fused
+  // epilogue (bit-identical to it): per 64-column group g, column c = 4 q + e of the group's four tiles summed in tile
+  // order, then the butterfly over the 16 columns (xor 8, 4: the other lane groups; xor 2, 1: this lane's e), then
+  // ((g0 + g1) + (g2 + g3)) + b3
+  float grp[2][4];
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {
+    float sc[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sc[rt][e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int mt = 4 * gq + j;
+      const float4 b2v = *(const float4*)(tp.b2 + 16 * mt + 4 * q), w3v = *(const float4*)(tp.w3 + 16 * mt + 4 * q);
+      const float bb[4] = {b2v.x, b2v.y, b2v.z, b2v.w}, ww[4] = {w3v.x, w3v.y, w3v.z, w3v.w};
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sc[rt][e] += relu_nan(acc2[mt][rt][e] + bb[e]) * ww[e];
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sc[rt][e] += __shfl_xor(sc[rt][e], 32);       // column c ^ 8  <->  lane group q ^ 2
+        sc[rt][e] += __shfl_xor(sc[rt][e], 16);       // column c ^ 4  <->  lane group q ^ 1
+      }
+      const float a0 = sc[rt][0] + sc[rt][2], a1 = sc[rt][1] + sc[rt][3];     // column c ^ 2
+      grp[rt][gq] = a0 + a1;                                                    // column c ^ 1
+    }
+  }
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int row = m0 + wave * 32 + rt * 16 + col;
+    if (q == 0 && row < tp.n_valid)
+      tp.sdf[tp.order ? tp.order[row] : row] = ((grp[rt][0] + grp[rt][1]) + (grp[rt][2] + grp[rt][3])) + tp.b3[0];
+  }
+}
+
+// fc1: the GemmParams of the fc_1 call (fp16; K % 64 == 0, N == 256); the rest: fc_2 / fc_out of the EPI_RELU_DOT call
+hipError_t launch_mlp_tail(const GemmParams& fc1, const char* w2, const float* b2, const float* w3, const float* b3,
+                           float* sdf, const int* order, int n_valid, hipStream_t s) {
+  if (fc1.fmt != FMT_FP16 || fc1.N != BN || fc1.M % BM || fc1.K % 64 || fc1.K < 64 || !fc1.bias) return hipErrorInvalidValue;
+  TailParams tp;
+  tp.fc1 = fc1; tp.w2 = w2; tp.b2 = b2; tp.w3 = w3; tp.b3 = b3; tp.sdf = sdf; tp.order = order; tp.n_valid = n_valid;
+  hipLaunchKernelGGL(k_mlp_tail_f16, dim3(fc1.M / BM), dim3(512), 0, s, tp);
+  return hipGetLastError();
+}
+
 template <int TERMS, int EPI, int FP16>
 static hipError_t launch_one(const GemmParams& p, hipStream_t s) {
   const int ntiles = (p.M / BM) * (p.N / BN);

@@ -459,6 +459,17 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
     gp.out_hi = (unsigned short*)(wsb + ws.h2_hi);
     gp.out_lo = terms == 3 ? (unsigned short*)(wsb + ws.h2_lo) : nullptr;
     gp.ldo = a->H2;
+#ifndef LIST_NO_FUSED_TAIL
+    if (a->no_activations && g.fmt == FMT_FP16 && a->H2 == 256 && a->H3 == 256 && a->H1 % 64 == 0) {
+      // inference: fc_1, fc_2 and fc_out in one kernel, H2 stays in registers (gemm_kernels.hip, k_mlp_tail_f16)
+      mark(LIST_STAGE_FC1);
+      e = launch_mlp_tail(gp, wp + pk.w2_hi, (const float*)(wp + pk.b2), (const float*)(wp + pk.w3),
+                          (const float*)(wp + pk.b3), a->sdf + p0, g.order, n_valid, s);
+      if (e != hipSuccess) return hip_fail(e, "fc_1/fc_2/fc_out launch");
+      mark(LIST_STAGE_FC2);
+      continue;
+    }
+#endif
     e = launch_gemm(gp, terms, EPI_RELU_SPLIT, s);
     if (e != hipSuccess) return hip_fail(e, "fc_1 launch");
     mark(LIST_STAGE_FC1);

@@ -450,6 +450,9 @@ hipError_t launch_gather_fixup(const GatherParams& g, const FeatLayout& L, const
                                const int* tile_flags, hipStream_t s);
 hipError_t launch_percep_pool(const ListPoolArgs& a, hipStream_t s);
 hipError_t launch_gemm(const GemmParams& p, int terms, int epi, hipStream_t s);
+// fc_1 + fc_2 + fc_out in one launch (fp16 operands, H2 = H3 = 256, nothing kept for a backward): gemm_kernels.hip
+hipError_t launch_mlp_tail(const GemmParams& fc1, const char* w2, const float* b2, const float* w3, const float* b3,
+                           float* sdf, const int* order, int n_valid, hipStream_t s);
 
 // backward: MLP (bwd_mlp_kernels.hip)
 hipError_t launch_prep_weights_bwd(const ListMlpWeights& w, const FeatLayout& L, const PackedMlpBwd& P,

@@ -71,7 +71,7 @@ class ListQueryArgs(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("precision", C.c_int32),
                 ("stage_events", C.POINTER(C.c_void_p)), ("no_sort", C.c_int32),
-                ("stage_event_sets", C.c_int32), ("percep_proj", C.c_void_p)]
+                ("stage_event_sets", C.c_int32), ("percep_proj", C.c_void_p), ("no_activations", C.c_int32)]
 
 
 class ListMlpGrads(C.Structure):
@@ -479,6 +479,8 @@ def sdf_query(query, trans_mat, img, vox, packed, perm=(2, 1, 0), scale=2.0, pre
     a, keep = _fill_query_args(query, perm, scale, vox, packed, precision, trans_mat, img, percep_feat,
                                clamp_hi, private_workspace=save_for_backward)
     a.no_sort = 0 if sort_points else 1
+    # nothing is kept for a backward: fc_1 / fc_2 / fc_out run as one kernel (fp16 operands), H2 stays in registers
+    a.no_activations = 0 if (save_for_backward or os.environ.get("LIST_FUSED_TAIL", "1") == "0") else 1
     if percep_proj is not None:
         if save_for_backward or percep_feat is not None:
             raise RuntimeError("percep_proj is an inference path: no backward, no pre-pooled features")
