@@ -197,9 +197,12 @@ typedef struct ListQueryArgs {
   int32_t no_activations;               /* ABI 6.  1: nothing of this forward is kept for          */
                                         /*   list_sdf_query_bwd (inference).  fc_1, fc_2 and fc_out  */
                                         /*   then run as ONE kernel that keeps H2 in registers (fp16 */
-                                        /*   operands, H2 = H3 = 256; other cases: no effect).  Same */
-                                        /*   values up to the order of the fp32 sums.  0 (default):  */
-                                        /*   H1 and H2 are left in the workspace for the backward.   */
+                                        /*   operands, H2 = H3 = 256; other cases: no effect).  The  */
+                                        /*   values are those of the two-launch path bit for bit     */
+                                        /*   (same products, k order and summation tree).  0         */
+                                        /*   (default): H1 and H2 are left in the workspace for the  */
+                                        /*   backward.  list_sdf_query_bwd refuses (LIST_ERR_ARG) a  */
+                                        /*   forward that had it set.                                */
 } ListQueryArgs;
 
 /* Boundaries recorded into ListQueryArgs.stage_events: one hipEvent after each kernel (group) of a

@@ -607,6 +607,7 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
     return fail(LIST_ERR_ARG, "precision=%d", a->precision);
   if (ga->vox_adjoint < 0 || ga->vox_adjoint > 2) return fail(LIST_ERR_ARG, "vox_adjoint=%d", ga->vox_adjoint);
   if (a->percep_proj) return fail(LIST_ERR_UNSUPPORTED, "a forward with percep_proj (inference) keeps no perceptual features for the backward");
+  if (a->no_activations) return fail(LIST_ERR_ARG, "a forward with no_activations = 1 (inference) keeps no H1 / H2 for the backward");
   const int64_t P = (int64_t)a->B * a->N;
   if (P > kMaxChunkRows)
     return fail(LIST_ERR_UNSUPPORTED, "backward handles up to %lld points per call (got %lld)",

@@ -421,9 +421,17 @@ def test_backward_rejects_unsupported_calls(hip):
     with pytest.raises(RuntimeError, match="float32 CUDA"):
         hip.sdf_query_backward(ctx, torch.zeros(sdf.shape), packed_b)
     # a forward workspace that cannot hold the query in one chunk is refused, not misread
+    keep = ctx.args.workspace_bytes
     ctx.args.workspace_bytes = 1 << 20
     with pytest.raises(RuntimeError, match="one chunk|workspace"):
         hip.sdf_query_backward(ctx, torch.zeros_like(sdf), packed_b)
+    # a forward that was told to keep no activations (inference: fc_1 + fc_2 + fc_out as one kernel where the
+    # operands allow it) left no H1 / H2 behind: the backward refuses it instead of reading stale planes
+    ctx.args.workspace_bytes = keep
+    ctx.args.no_activations = 1
+    with pytest.raises(hip.ListError, match="no_activations") as e:
+        hip.sdf_query_backward(ctx, torch.zeros_like(sdf), packed_b)
+    assert e.value.code == hip.ERR_ARG
 
 
 # ------------------------------------------------------------------------------------------ autograd
