@@ -684,30 +684,33 @@ hipError_t launch_transpose_vox(const ListMap3D& m, int B, int f16, void* out, h
 // --------------------------------------------------------------------------------------------
 // MLP parameter repack
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_prep_w0(const float* __restrict__ w0, FeatLayout L, int H1,
-                                                 int fmt, unsigned short* __restrict__ hi,
-                                                 unsigned short* __restrict__ lo) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void prep_w0_elem(int64_t i, const float* __restrict__ w0, const FeatLayout& L, int H1,
+                                             int fmt, unsigned short* __restrict__ hi) {
   if (i >= (int64_t)H1 * L.Kp) return;
   const int n = (int)(i / L.Kp), kp = (int)(i - (int64_t)n * L.Kp);
   const int kr = ref_index_of(L, kp);
   const float v = kr >= 0 ? w0[(int64_t)n * L.F + kr] : 0.f;
   if (fmt == FMT_FP16) { hi[i] = f2h(v); return; }
   const unsigned short h = f2bf(v);
-  (void)lo;                                   // split formats: hi / lo halfs interleaved in 64-B blocks (xi_off)
-  hi[xi_off(i)] = h;
+  hi[xi_off(i)] = h;                          // split formats: hi / lo halfs interleaved in 64-B blocks (xi_off)
   hi[xi_off(i) + kXiLo] = bf_lo(v, h);
 }
 
-__global__ __launch_bounds__(256) void k_split(const float4* __restrict__ x, uint2* __restrict__ hi,
-                                               uint2* __restrict__ lo, int64_t n4, int fmt) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+// blocks `blk` of `nblk` (256 threads each) over n4 float4s
+__device__ __forceinline__ void split_range(int blk, int nblk, const float4* __restrict__ x, uint2* __restrict__ hi,
+                                            uint2* __restrict__ lo, int64_t n4, int fmt) {
+  for (int64_t i = (int64_t)blk * 256 + threadIdx.x; i < n4; i += (int64_t)nblk * 256) {
     if (fmt == FMT_FP16) { hi[i] = half4(x[i]); continue; }
     uint2 h, l;
     split4(x[i], h, l);
     hi[i] = h;
     if (lo) lo[i] = l;
   }
+}
+
+__global__ __launch_bounds__(256) void k_split(const float4* __restrict__ x, uint2* __restrict__ hi,
+                                               uint2* __restrict__ lo, int64_t n4, int fmt) {
+  split_range(blockIdx.x, gridDim.x, x, hi, lo, n4, fmt);
 }
 
 // fp32 [rows][C] (C % 32 == 0) -> bf16 hi / lo halfs interleaved in 64-B blocks (xi_off): the A operand of the
@@ -743,44 +746,65 @@ hipError_t launch_split(const float* x, unsigned short* hi, unsigned short* lo, 
   return hipGetLastError();
 }
 
-// biases, w3, b3: five short fp32 vectors, one launch
-__global__ __launch_bounds__(256) void k_copy_small(const float* b0, const float* b1, const float* b2,
-                                                    const float* w3, const float* b3, int H1, int H2, int H3,
-                                                    float* o0, float* o1, float* o2, float* o3, float* o4) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < H1) { o0[i] = b0[i]; return; }
-  i -= H1;
-  if (i < H2) { o1[i] = b1[i]; return; }
-  i -= H2;
-  if (i < H3) { o2[i] = b2[i]; return; }
-  i -= H3;
-  if (i < H3) { o3[i] = w3[i]; return; }
-  i -= H3;
-  if (i == 0) o4[0] = b3[0];
+// The whole repack of list_prep_mlp_weights as ONE launch (four until round 3): block ranges [0, nb0) permute / pad /
+// convert W0 into gather order, [nb0, +nb1) and [.., +nb2) convert W1 and W2, the last block(s) copy the five short
+// fp32 vectors (biases, w3, b3).  Four disjoint parts of `packed`, no block reads what another writes.
+struct PrepWeightsArgs {
+  const float *w0, *w1, *w2, *b0, *b1, *b2, *w3, *b3;
+  FeatLayout L;
+  int H1, H2, H3, fmt;
+  int nb0, nb1, nb2;
+  int64_t n4_1, n4_2;
+  unsigned short *w0_hi, *w1_hi, *w1_lo, *w2_hi, *w2_lo;
+  float *o0, *o1, *o2, *o3, *o4;
+};
+
+__global__ __launch_bounds__(256) void k_prep_weights(PrepWeightsArgs a) {
+  int blk = blockIdx.x;
+  if (blk < a.nb0) { prep_w0_elem((int64_t)blk * 256 + threadIdx.x, a.w0, a.L, a.H1, a.fmt, a.w0_hi); return; }
+  blk -= a.nb0;
+  if (blk < a.nb1) { split_range(blk, a.nb1, (const float4*)a.w1, (uint2*)a.w1_hi, (uint2*)a.w1_lo, a.n4_1, a.fmt); return; }
+  blk -= a.nb1;
+  if (blk < a.nb2) { split_range(blk, a.nb2, (const float4*)a.w2, (uint2*)a.w2_hi, (uint2*)a.w2_lo, a.n4_2, a.fmt); return; }
+  blk -= a.nb2;
+  int i = blk * 256 + threadIdx.x;
+  if (i < a.H1) { a.o0[i] = a.b0[i]; return; }
+  i -= a.H1;
+  if (i < a.H2) { a.o1[i] = a.b1[i]; return; }
+  i -= a.H2;
+  if (i < a.H3) { a.o2[i] = a.b2[i]; return; }
+  i -= a.H3;
+  if (i < a.H3) { a.o3[i] = a.w3[i]; return; }
+  i -= a.H3;
+  if (i == 0) a.o4[0] = a.b3[0];
+}
+
+static int split_blocks(int64_t n4) {
+  int64_t b = (n4 + 255) / 256;
+  return (int)(b > 8192 ? 8192 : b < 1 ? 1 : b);
 }
 
 hipError_t launch_prep_weights(const ListMlpWeights& w, const FeatLayout& L, const PackedMlp& P,
                                char* packed, hipStream_t s) {
   const int64_t n0 = (int64_t)w.H1 * L.Kp;
-  const int fmt = w.precision == LIST_PREC_FP16 ? FMT_FP16 : FMT_BF16_SPLIT;
-  // four launches into four disjoint parts of `packed`: only the first keeps the stream's order (list_common.h)
-  hipLaunchKernelGGL(k_prep_w0, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, s, w.w0, L, w.H1, fmt,
-                     (unsigned short*)(packed + P.w0_hi), (unsigned short*)(packed + P.w0_lo));
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  e = launch_split(w.w1, (unsigned short*)(packed + P.w1_hi), (unsigned short*)(packed + P.w1_lo),
-                   (int64_t)w.H2 * w.H1, fmt, s, any_order());
-  if (e != hipSuccess) return e;
-  e = launch_split(w.w2, (unsigned short*)(packed + P.w2_hi), (unsigned short*)(packed + P.w2_lo),
-                   (int64_t)w.H3 * w.H2, fmt, s, any_order());
-  if (e != hipSuccess) return e;
-  LIST_LAUNCH(k_copy_small, dim3((unsigned)((w.H1 + w.H2 + 2 * w.H3 + 1 + 255) / 256)), dim3(256), 0, s, any_order(),
-              w.b0, w.b1, w.b2, w.w3, w.b3, w.H1, w.H2, w.H3, (float*)(packed + P.b0),
-              (float*)(packed + P.b1), (float*)(packed + P.b2), (float*)(packed + P.w3),
-              (float*)(packed + P.b3));
-  e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  return hipSuccess;
+  PrepWeightsArgs a;
+  a.w0 = w.w0; a.w1 = w.w1; a.w2 = w.w2; a.b0 = w.b0; a.b1 = w.b1; a.b2 = w.b2; a.w3 = w.w3; a.b3 = w.b3;
+  a.L = L; a.H1 = w.H1; a.H2 = w.H2; a.H3 = w.H3;
+  a.fmt = w.precision == LIST_PREC_FP16 ? FMT_FP16 : FMT_BF16_SPLIT;
+  a.n4_1 = (int64_t)w.H2 * w.H1 / 4;
+  a.n4_2 = (int64_t)w.H3 * w.H2 / 4;
+  a.nb0 = (int)((n0 + 255) / 256);
+  a.nb1 = split_blocks(a.n4_1);
+  a.nb2 = split_blocks(a.n4_2);
+  const int nbs = (w.H1 + w.H2 + 2 * w.H3 + 1 + 255) / 256;
+  a.w0_hi = (unsigned short*)(packed + P.w0_hi);
+  a.w1_hi = (unsigned short*)(packed + P.w1_hi); a.w1_lo = (unsigned short*)(packed + P.w1_lo);
+  a.w2_hi = (unsigned short*)(packed + P.w2_hi); a.w2_lo = (unsigned short*)(packed + P.w2_lo);
+  a.o0 = (float*)(packed + P.b0); a.o1 = (float*)(packed + P.b1); a.o2 = (float*)(packed + P.b2);
+  a.o3 = (float*)(packed + P.w3); a.o4 = (float*)(packed + P.b3);
+  // (in stream order: the first kernel behind whatever produced the weights)
+  hipLaunchKernelGGL(k_prep_weights, dim3((unsigned)(a.nb0 + a.nb1 + a.nb2 + nbs)), dim3(256), 0, s, a);
+  return hipGetLastError();
 }
 
 }  // namespace list
