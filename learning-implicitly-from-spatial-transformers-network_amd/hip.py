@@ -445,6 +445,13 @@ def _fill_query_args(query, perm, scale, vox, packed, precision, trans_mat=None,
     return a, keep
 
 
+def keeps_no_activations(save_for_backward=False):
+    """What sdf_query puts into ListQueryArgs.no_activations: a forward that is not kept for the backward lets the
+    library run fc_1 + fc_2 + fc_out as one kernel (fp16 operands; include/list_hip.h).  LIST_FUSED_TAIL=0 in the
+    environment keeps the two launches (A/B runs)."""
+    return not save_for_backward and os.environ.get("LIST_FUSED_TAIL", "1") != "0"
+
+
 def query_chunks(n_points, packed):
     """Row chunks list_sdf_query_fwd cuts a query of n_points into (with the workspace sdf_query gives it)."""
     lib = load()
@@ -480,7 +487,7 @@ def sdf_query(query, trans_mat, img, vox, packed, perm=(2, 1, 0), scale=2.0, pre
                                clamp_hi, private_workspace=save_for_backward)
     a.no_sort = 0 if sort_points else 1
     # nothing is kept for a backward: fc_1 / fc_2 / fc_out run as one kernel (fp16 operands), H2 stays in registers
-    a.no_activations = 0 if (save_for_backward or os.environ.get("LIST_FUSED_TAIL", "1") == "0") else 1
+    a.no_activations = 1 if keeps_no_activations(save_for_backward) else 0
     if percep_proj is not None:
         if save_for_backward or percep_feat is not None:
             raise RuntimeError("percep_proj is an inference path: no backward, no pre-pooled features")

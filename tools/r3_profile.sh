@@ -5,7 +5,8 @@ set -o pipefail
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 T=${TAG:-r03}
-python learning-implicitly-from-spatial-transformers-network_amd/build.py --force > /dev/null 2>&1
+# the library travels with the snapshot; rebuild only if a source is newer, and stop if that fails (a stale .so would be profiled silently)
+python learning-implicitly-from-spatial-transformers-network_amd/build.py > gpurun_out/${T}prof_build.log 2>&1 || { echo "build failed"; tail -5 gpurun_out/${T}prof_build.log; exit 1; }
 export TMPDIR=/tmp
 rm -rf gpurun_out/${T}prof
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${T}prof/kt -- python3 bench.py --no-cpu-baseline --sustained-steps 0 > gpurun_out/${T}prof_kt.json 2> gpurun_out/${T}prof_kt.err; echo "kt rc=$?"
