@@ -497,18 +497,34 @@ def roofline_of(kernel_ms, table, precision, workload):
     return r
 
 
-def path_roofs(value, precision):
-    """SURVEY 8d whole-path ceilings in query-points/s and where `value` stands against the binding one."""
+def path_roofs(value, precision, grid=False):
+    """SURVEY 8d whole-path ceilings in query-points/s and where `value` stands against the binding one.
+
+    The gather figure prices every tap REQUEST as HBM bytes (SURVEY 8d's per-point count: scattered queries share few
+    taps).  grid=True (the dense 256^3 inference grid on ONE image, BASELINE config 4): neighbouring grid points share
+    nearly all their taps and one image's maps stay cache-resident, so that figure is not a roof there -- the path has run
+    above it since round 2b -- and is reported as what it is, a no-reuse request rate; the binding roof is the MFMA one,
+    on the FLOPs the path executes with the perceptual block of fc_0 applied to the map (K = 3610 - 1024)."""
     map_bytes = 2 if precision == "fp16" else 4
     w_byte = (7 * 8 * 369 + 4 * 1024) * map_bytes + 16
     products = 3 if precision == "bf16x3" else 1
     gather_roof = PEAK_HBM_GBS * 1e9 / w_byte
-    mfma_roof = PEAK_BF16_TFLOPS * 1e12 / (W_FLOP_PER_PT * products)
-    bind = min(gather_roof, mfma_roof)
-    return {"gather_roof_points_per_s": gather_roof, "gather_bytes_per_point": w_byte,
-            "mfma_roof_points_per_s": mfma_roof, "mfma_products_per_mac": products,
-            "binding": "hbm gather" if gather_roof <= mfma_roof else "mfma",
-            "whole_path_frac_of_binding_roof": value / bind}
+    flop = W_FLOP_PER_PT - 2 * 1024 * 512 if grid else W_FLOP_PER_PT
+    mfma_roof = PEAK_BF16_TFLOPS * 1e12 / (flop * products)
+    if grid:
+        r = {"no_reuse_tap_request_points_per_s": gather_roof, "gather_bytes_per_point_if_no_tap_were_shared": w_byte,
+             "mfma_roof_points_per_s": mfma_roof, "mfma_flop_per_point_executed": flop, "mfma_products_per_mac": products,
+             "binding": "mfma (taps of a dense grid on one image are served by the caches)",
+             "whole_path_frac_of_binding_roof": value / mfma_roof}
+    else:
+        bind = min(gather_roof, mfma_roof)
+        r = {"gather_roof_points_per_s": gather_roof, "gather_bytes_per_point": w_byte,
+             "mfma_roof_points_per_s": mfma_roof, "mfma_products_per_mac": products,
+             "binding": "hbm gather" if gather_roof <= mfma_roof else "mfma",
+             "whole_path_frac_of_binding_roof": value / bind}
+    assert 0.0 < r["whole_path_frac_of_binding_roof"] <= 1.0, \
+        f"whole-path fraction {r['whole_path_frac_of_binding_roof']} of its binding roof is not physical: accounting bug"
+    return r
 
 
 def main():
@@ -667,13 +683,13 @@ def main():
                                                                       2 if a16 else 4, proj=bool(inp.get("ordered_points")),
                                                                       fused_tail=bool(alt["kernel_ms"].get("_fused_tail"))),
                                       alt["precision"], args.workload)
-        alt["path_roofs"] = path_roofs(alt["value"] * P / global_points, alt["precision"])
+        alt["path_roofs"] = path_roofs(alt["value"] * P / global_points, alt["precision"], grid=bool(inp.get("ordered_points")))
     gather_ms = kernel_ms["gathers_back_to_back"]       # the seven launches as the timed region runs them
     mlp_ms = kernel_ms["fc_0"] + kernel_ms["fc_1"] + kernel_ms["fc_2_out"]
     pmc = pmc_traffic(headline, args.workload)
     path = {
         # the whole path against its binding roof (per GPU)
-        **path_roofs(value * P / global_points, headline),      # rank 0's share
+        **path_roofs(value * P / global_points, headline, grid=bool(inp.get("ordered_points"))),      # rank 0's share
         "mlp_TFLOPs_algorithmic": P * W_FLOP_PER_PT / (mlp_ms * 1e-3) / 1e12,
         "mlp_frac_of_bf16_peak": P * W_FLOP_PER_PT / (mlp_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
         "gather_ms": gather_ms, "mlp_ms": mlp_ms,
@@ -816,7 +832,10 @@ def main():
                                         + ("fp16" if hip.map_dtype_for(headline) == "f16" else "fp32"),
                    "inputs": "reference layout (NCHW/NCDHW fp32) resident in HBM; layout hand-off + weight "
                              "repack inside the timed step",
-                   "parallelism": f"batch-sharded x{world}" + (" + RCCL all-gather of sdf" if world > 1 else "")},
+                   # names the collective that RAN: RCCL on the "nccl" backend, gloo in the one-GPU rehearsals
+                   "parallelism": f"batch-sharded x{world}" + (
+                       (" + RCCL all-gather of sdf" if dist.get_backend() == "nccl" else
+                        f" + {dist.get_backend()} all-gather of sdf (rehearsal, not RCCL)") if world > 1 else "")},
         "ranks": ranks,
         "step_events_ms": extra["step_events_ms"],
         "sustained": extra.get("sustained"),

@@ -6,7 +6,7 @@ set -o pipefail
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 T=${TAG:-r03}
-python learning-implicitly-from-spatial-transformers-network_amd/build.py > /dev/null 2>&1
+python learning-implicitly-from-spatial-transformers-network_amd/build.py > gpurun_out/${T}_multi_build.log 2>&1 || { echo "build failed"; tail -5 gpurun_out/${T}_multi_build.log; exit 1; }
 for mode in weak strong; do
   extra=""; [ $mode = strong ] && extra="--global-batch 5"
   LIST_BENCH_BACKEND=gloo timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 --sustained-steps 50 --no-cpu-baseline --scaling $mode $extra > gpurun_out/${T}_bench_2rank_gloo_$mode.json 2> gpurun_out/${T}_bench_2rank_gloo_$mode.err
