@@ -459,11 +459,12 @@ def run_whole_model(workload, precision, device, steps=5, warmup=2):
     return out
 
 
-def pmc_traffic(precision, workload):
-    """HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.py), or {}.  Only the metric
-    workload has them."""
+def pmc_traffic(precision, workload, batch):
+    """HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.py), or {}.  The counters were collected
+    on the metric workload at ITS batch per GPU: any other workload, or another number of images on this rank (strong
+    scaling: 64 / 32 / 16 images per rank at N = 1 / 2 / 4), has no measured traffic and reports none."""
     tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if workload != "list_im2sdf_b8_n20k_224" or not os.path.exists(tf):
+    if workload != "list_im2sdf_b8_n20k_224" or batch != WORKLOADS[workload][0] or not os.path.exists(tf):
         return {}
     data = json.load(open(tf))
     # the counters belong to the kernel sources they were collected on (tools/pmc_traffic.py stamps build.py's SHA-256):
@@ -474,7 +475,7 @@ def pmc_traffic(precision, workload):
     return data.get(precision, {})
 
 
-def roofline_of(kernel_ms, table, precision, workload):
+def roofline_of(kernel_ms, table, precision, workload, batch):
     """Roofline entry of the dominant kernel: the longest-running kernel among those with a hardware roof
     (MFMA or HBM).  kernel_ms holds the time of all its launches in a step (one per row chunk); the algorithmic
     units in `table` are per step too, so achieved = units / time whatever the chunking."""
@@ -483,7 +484,7 @@ def roofline_of(kernel_ms, table, precision, workload):
     dom = max(roofed, key=lambda k: kernel_ms.get(k, 0.0))
     bound, units, _ = table[dom]
     secs = kernel_ms[dom] * 1e-3
-    traffic = pmc_traffic(precision, workload).get(dom)
+    traffic = pmc_traffic(precision, workload, batch).get(dom)
     ach = units / secs / 1e12
     # fc_0 runs the ping-pong schedule in every precision (single plane, or hi / lo interleaved for the split formats)
     fc1 = "k_gemm_nt (fc_1 + ReLU)" if precision == "bf16x3" else "k_gemm_nt_pp (fc_1 + ReLU)"
@@ -676,17 +677,17 @@ def main():
     xb = 2 if headline != "bf16x3" else 4
     table = kernel_table(B, N, img_res, vox_res, map_size, xb, 2 if headline == "fp16" else 4, proj=bool(inp.get("ordered_points")),
                          fused_tail=bool(kernel_ms.get("_fused_tail")))
-    roof = roofline_of(kernel_ms, table, headline, args.workload)
+    roof = roofline_of(kernel_ms, table, headline, args.workload, B)
     if alt is not None:
         a16 = alt["precision"] == "fp16"
         alt["roofline"] = roofline_of(alt["kernel_ms"], kernel_table(B, N, img_res, vox_res, map_size, 2 if a16 else 4,
                                                                       2 if a16 else 4, proj=bool(inp.get("ordered_points")),
                                                                       fused_tail=bool(alt["kernel_ms"].get("_fused_tail"))),
-                                      alt["precision"], args.workload)
+                                      alt["precision"], args.workload, B)
         alt["path_roofs"] = path_roofs(alt["value"] * P / global_points, alt["precision"], grid=bool(inp.get("ordered_points")))
     gather_ms = kernel_ms["gathers_back_to_back"]       # the seven launches as the timed region runs them
     mlp_ms = kernel_ms["fc_0"] + kernel_ms["fc_1"] + kernel_ms["fc_2_out"]
-    pmc = pmc_traffic(headline, args.workload)
+    pmc = pmc_traffic(headline, args.workload, B)
     path = {
         # the whole path against its binding roof (per GPU)
         **path_roofs(value * P / global_points, headline, grid=bool(inp.get("ordered_points"))),      # rank 0's share
