@@ -163,6 +163,9 @@ _lib = None
 _lock = threading.Lock()
 
 
+ABI_VERSION = 6          # LIST_ABI_VERSION of the include/list_hip.h these ctypes structs mirror (checked in load())
+
+
 def load():
     """dlopen liblist_hip.so and bind every symbol of include/list_hip.h.  Raises if absent."""
     global _lib
@@ -179,6 +182,12 @@ def load():
             for name, (res, args) in EXPORTS.items():
                 fn = getattr(lib, name)
                 fn.restype, fn.argtypes = res, args
+            # the argument structs grow at their end from one ABI version to the next: a library that reads a longer
+            # struct than this binding fills would take flags (no_activations, grad_img_map_dtype) from stray bytes
+            got = lib.list_abi_version()
+            if got != ABI_VERSION:
+                raise RuntimeError(f"{LIB_PATH} speaks ABI {got}, this binding ABI {ABI_VERSION} (include/list_hip.h: "
+                                   "LIST_ABI_VERSION): rebuild it with `python __graft_entry__.py`")
             _lib = lib
     return _lib
 

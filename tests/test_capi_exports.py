@@ -39,6 +39,7 @@ def test_abi_version_and_error_string_without_gpu():
     assert lib.list_abi_version() == 6
     text = open(os.path.join(ROOT, "include", "list_hip.h")).read()
     assert "#define LIST_ABI_VERSION 6" in text
+    assert hip.ABI_VERSION == 6                      # header, library and ctypes structs move together
     # argument validation happens before any HIP call: a NULL args struct is rejected cleanly
     assert lib.list_sdf_query_fwd(None, None) == -1
     assert b"NULL" in lib.list_last_error()
@@ -62,3 +63,18 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(hip, "LIB_PATH", "/nonexistent/liblist_hip.so")
     with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
         hip.load()
+
+
+def test_binding_refuses_a_library_of_another_abi_version(monkeypatch):
+    """The argument structs grow at their end between ABI versions (ABI 6: ListQueryArgs.no_activations,
+    ListQueryGradArgs.grad_img_map_dtype): a library reading a longer struct than the binding fills would take those
+    flags from stray bytes, so load() compares list_abi_version() with the version its structs mirror."""
+    import pytest
+    from list_amd import hip
+    hip.load()                                       # the real pair agrees
+    monkeypatch.setattr(hip, "_lib", None)           # force a fresh load against a binding that claims another version
+    monkeypatch.setattr(hip, "ABI_VERSION", hip.ABI_VERSION - 1)
+    with pytest.raises(RuntimeError, match="speaks ABI 6, this binding ABI 5"):
+        hip.load()
+    assert hip._lib is None                          # nothing half-loaded is left behind
+
