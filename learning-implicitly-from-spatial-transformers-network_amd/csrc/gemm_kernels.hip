@@ -888,7 +888,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt16(GemmParams p) {
 // of the two tiles (four columns each, bias + ReLU + fp16 in place) are then columns 32 ks + 8 q .. + 7 (q = lane >> 4),
 // i.e. exactly its B fragment of fc_2's k-step ks in natural k order.  Same products, same k order, same summation tree
 // in the fc_out epilogue as the two-launch path: bit-identical to it (asserted: a training forward, which keeps H1 / H2
-// for the backward and takes the two launches, equals the inference forward bit for bit, tests/test_threads_gpu.py).
+// for the backward and takes the two launches, equals the inference forward bit for bit: tests/test_fused_tail_gpu.py, tests/test_threads_gpu.py).
 // LDS: fc_1 streams H1 / W1 through the two 64-KB stages of the plain loop; W2 (128 KB) is resident for fc_2 -- its
 // first K-tile prefetched into the last 32 KB at the start, the other three into the dead stages behind fc_1's last
 // K-tile, waited for tile by tile (counted vmcnt).  What it removes against the two launches: H2's round trip (82 MB

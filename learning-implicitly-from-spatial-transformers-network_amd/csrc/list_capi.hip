@@ -366,6 +366,10 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
   if (a->precision != LIST_PREC_BF16X3 && a->precision != LIST_PREC_BF16 &&
       a->precision != LIST_PREC_FP16)
     return fail(LIST_ERR_ARG, "precision=%d", a->precision);
+  // (a flag, not a count: anything else is a struct of another ABI version or an uninitialised one)
+  if (a->no_activations != 0 && a->no_activations != 1)
+    return fail(LIST_ERR_ARG, "no_activations=%d (0 or 1; zero-initialise ListQueryArgs, list_abi_version() = %d)",
+                a->no_activations, LIST_ABI_VERSION);
   if (!aligned16(a->workspace)) return fail(LIST_ERR_SHAPE, "workspace must be 16-byte aligned");
   const int64_t P = (int64_t)a->B * a->N;
   const int64_t rows = chunk_rows_for(a->workspace_bytes, P, L.Kp, a->H1, a->H2);

@@ -496,7 +496,7 @@ def sdf_query(query, trans_mat, img, vox, packed, perm=(2, 1, 0), scale=2.0, pre
                                clamp_hi, private_workspace=save_for_backward)
     a.no_sort = 0 if sort_points else 1
     # nothing is kept for a backward: fc_1 / fc_2 / fc_out run as one kernel (fp16 operands), H2 stays in registers
-    a.no_activations = 1 if keeps_no_activations(save_for_backward) else 0
+    a.no_activations = int(keeps_no_activations(save_for_backward))
     if percep_proj is not None:
         if save_for_backward or percep_feat is not None:
             raise RuntimeError("percep_proj is an inference path: no backward, no pre-pooled features")

@@ -107,3 +107,14 @@ def test_fused_tail_is_the_path_an_inference_forward_takes(hip, monkeypatch):
 
     fused, kept = fc1_ms(), fc1_ms(save_for_backward=True)
     assert fused < 0.5 * kept, (fused, kept)
+
+
+def test_forward_rejects_a_flag_value_that_is_not_a_flag(hip, monkeypatch):
+    """no_activations is 0 or 1.  Anything else is what a struct of another ABI version (or an uninitialised one)
+    looks like, and taking it for `true` would run a training forward without writing H1 / H2: refused, loudly."""
+    q, tm, img, vox, packed = _prepare(hip, "tiny")
+    monkeypatch.setattr(hip, "keeps_no_activations", lambda save_for_backward=False: 2)
+    with pytest.raises(hip.ListError, match="no_activations=2") as e:
+        hip.sdf_query(q, tm, img, vox, packed, precision="fp16")
+    assert e.value.code == hip.ERR_ARG
+
