@@ -623,6 +623,12 @@ def main():
         alt_cl = {"inputs": "channels_last / channels_last_3d fp32 maps resident in HBM", "precision": headline,
                   "value": global_points * c_steps / c_el, "steps": c_steps, "ms_per_step": c_el / c_steps * 1e3,
                   "kernel_ms": c_ms, "max_abs_diff_vs_headline": float((c_sdf - sdf).abs().max())}
+        # the headline keeps the reference's NCHW / NCDHW hand-off inside its timed step (the boundary the reference's
+        # encoders emit); the package's own LIST runs channels-last encoders, for which this entry is the query rate
+        alt_cl["ratio_to_headline"] = alt_cl["value"] / (global_points * args.steps / elapsed)
+        alt_cl["note"] = ("the layout network.models.LIST of this package hands over (channels_last encoders): the "
+                          "reference-layout headline pays the NCDHW->NDHWC transposes in every step and under-states "
+                          "the in-model query rate by this ratio")
         del inp_cl
     alt = None
     if args.precision is None:
