@@ -118,3 +118,32 @@ def test_forward_rejects_a_flag_value_that_is_not_a_flag(hip, monkeypatch):
         hip.sdf_query(q, tm, img, vox, packed, precision="fp16")
     assert e.value.code == hip.ERR_ARG
 
+
+# The library takes any first hidden width that is a multiple of 256 (the reference's is 2 * h_dim = 512,
+# modules.py:196-200); the fused tail streams it in K-tiles of 64: 4, 12 and 16 tiles here instead of 8, around the
+# schedule that hands the LDS stages over to W2 behind fc_1's last tiles
+@pytest.mark.parametrize("h1", [256, 768, 1024])
+def test_fused_tail_bit_for_bit_at_other_first_hidden_widths(hip, monkeypatch, h1):
+    from list_amd import synthetic as synth
+    c = cases.build_case("small")
+    md = hip.map_dtype_for("fp16")
+    img = hip.prep_img_maps([dev(m) for m in c["img_maps"]], dtype=md)
+    vox = hip.prep_vox_maps([dev(m) for m in c["vox_maps"]], dtype=md)
+    F = c["weights"]["fc_0.weight"].shape[1]
+    w = dict(synth.make_mlp_weights(91, feature_size=F))
+    bound = 1.0 / np.sqrt(h1)
+    w["fc_0.weight"] = synth.uniform(9100, (h1, F, 1), -1.0 / np.sqrt(F), 1.0 / np.sqrt(F))
+    w["fc_0.bias"] = synth.uniform(9101, (h1,), -1.0 / np.sqrt(F), 1.0 / np.sqrt(F))
+    w["fc_1.weight"] = synth.uniform(9102, (256, h1, 1), -bound, bound)
+    w["fc_1.bias"] = synth.uniform(9103, (256,), -bound, bound)
+    packed = hip.prep_mlp_weights({k: dev(v) for k, v in w.items()}, vox.channels, img.channels, "fp16")
+    assert packed.H1 == h1 and packed.H2 == 256
+    q, tm = dev(c["query"]), dev(c["trans_mat"])
+    monkeypatch.setenv("LIST_FUSED_TAIL", "0")
+    two = hip.sdf_query(q, tm, img, vox, packed, precision="fp16").clone()
+    monkeypatch.setenv("LIST_FUSED_TAIL", "1")
+    one = hip.sdf_query(q, tm, img, vox, packed, precision="fp16").clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(two).all() and float(two.abs().max()) > 1e-3
+    assert torch.equal(one, two)
+
