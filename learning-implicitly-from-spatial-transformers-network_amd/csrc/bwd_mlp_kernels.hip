@@ -14,6 +14,7 @@
 // column-major to a 16-lane group), so no transposed copy of the 1.2-GB feature matrix is ever made.
 // LDS image: 512-B rows (256 columns), 16-B chunk index XORed with ((row&3)<<2 | (row>>2)&3): the four
 // rows of a transposed read and the chunks of its two blocks fall on 16 distinct 16-B bank slots.
+#include <stdlib.h>
 #include <string.h>
 
 #include "list_common.h"
@@ -185,6 +186,115 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn(GemmTnParams p) {
   }
 }
 
+// ---- the same product on the 16 x 16 x 32 MFMA shape (round 3) ------------------------------------------------------
+// Same tiles, same LDS image, same staging and the same number of transposed reads as k_gemm_tn; the chip holds a
+// higher clock under twice as many half-size MFMAs (the round-2b finding on fc_0).  Operand
+// layout of v_mfma_f32_16x16x32: lane l holds 8 consecutive k (= points) 8 (l >> 4) .. + 7 of row / column l & 15, so
+// the 16-lane group g = l >> 4 reads points 8 g + 4 hh + q (two transposed reads hh = 0, 1 of 4 points each) of ONE
+// 16-column block: lane 4 q + pp of the group addresses point row q, columns 4 pp .. 4 pp + 3.  With the image's chunk
+// swizzle tn_swz(row) = (q << 2) | ((2 g + hh) & 3) the 16 (g, q) pairs of one read fall on every pair of 16-B bank
+// slots exactly twice (f >> 1 = 2 q + (g & 1)): two passes per 512-B read, the minimum.
+template <int FP16>
+__device__ __forceinline__ f32x4 mfma_tn16(const s16x8& a, const s16x8& b, const f32x4& c) {
+  if (FP16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int TERMS, int FP16>
+__global__ __launch_bounds__(512, 2) void k_gemm_tn16(GemmTnParams p) {
+  using P = TnPipe<TERMS>;
+  __shared__ __attribute__((aligned(16))) char smem[kTnLds];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int tiles_n = (p.N + 255) / 256;
+  const int ntiles = (p.M / 256) * tiles_n;
+  const int tile = blockIdx.x % ntiles, split = blockIdx.x / ntiles;
+  const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
+  const int nk = p.P / P::BK;
+  const int t0 = split * p.steps_per_split;
+  const int t1 = min(nk, t0 + p.steps_per_split);
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  // byte offset of (point row 8 g + 4 hh + q, swizzle f) inside a 32-point block; the 16-B chunk of column block c
+  // (0 .. 15 inside the wave's half of the row) is ((2 c + (pp >> 1)) ^ f) -- one XOR per read, no offset tables
+  int rowoff[2], fz[2];
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    rowoff[hh] = 512 * (8 * g + 4 * hh + q) + 8 * (pp & 1);
+    fz[hh] = (q << 2) | ((2 * g + hh) & 3);
+  }
+  const int alow = pp >> 1, abase = 256 * wm;                       // A: columns 128 wm + 16 i: chunks 16 wm + 2 i
+  const int bbase = P::kBOff + 256 * (wn >> 1), bch = 8 * (wn & 1);  // B: columns 64 wn + 16 j: chunks 8 wn + 2 j
+
+  if (t0 < t1) stage_tn<TERMS>(p, smem, (int64_t)t0 * P::BK, m0, n0, wave, lane);
+  for (int t = t0; t < t1; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 1 < t1)
+      stage_tn<TERMS>(p, smem + ((t + 1 - t0) & 1) * P::kStageBytes, (int64_t)(t + 1) * P::BK, m0, n0, wave, lane);
+    const char* cur = smem + ((t - t0) & 1) * P::kStageBytes;
+    constexpr int NS = P::BK / 32;
+    // register double-buffered fragments, as in k_gemm_tn: the transposed reads of k32-step s2 + 1 are issued ahead of
+    // the MFMAs of step s2 (single-plane formats: two steps per K-tile; the split formats have one)
+    s16x8 ah[2][8], bh[2][4], al[TERMS == 3 ? 8 : 1], bl[TERMS == 3 ? 4 : 1];
+    auto load_frags = [&](int s2, int buf) {
+      const char* cs = cur + s2 * 32 * P::kRowBytes;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int o0 = bbase + rowoff[0] + 16 * ((bch + 2 * j + alow) ^ fz[0]);
+        const int o1 = bbase + rowoff[1] + 16 * ((bch + 2 * j + alow) ^ fz[1]);
+        bh[buf][j] = cat4(tr_read(cs + o0), tr_read(cs + o1));
+        if (TERMS == 3) bl[j] = cat4(tr_read(cs + P::kPlaneBytes + o0), tr_read(cs + P::kPlaneBytes + o1));
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int o0 = abase + rowoff[0] + 16 * ((2 * i + alow) ^ fz[0]);
+        const int o1 = abase + rowoff[1] + 16 * ((2 * i + alow) ^ fz[1]);
+        ah[buf][i] = cat4(tr_read(cs + o0), tr_read(cs + o1));
+        if (TERMS == 3) al[i] = cat4(tr_read(cs + P::kPlaneBytes + o0), tr_read(cs + P::kPlaneBytes + o1));
+      }
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) {
+      const int bb = s2 & 1;
+      if (s2 + 1 < NS) load_frags(s2 + 1, bb ^ 1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (TERMS == 3) {
+            acc[i][j] = mfma_tn16<0>(al[i], bh[bb][j], acc[i][j]);
+            acc[i][j] = mfma_tn16<0>(ah[bb][i], bl[j], acc[i][j]);
+          }
+          acc[i][j] = mfma_tn16<FP16>(ah[bb][i], bh[bb][j], acc[i][j]);
+        }
+    }
+  }
+
+  // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
+  const int col_in = lane & 15, row_in = 4 * (lane >> 4);
+  float* out = p.slab + ((int64_t)split * p.M + m0 + wm * 128 + row_in) * p.ldn + n0 + wn * 64 + col_in;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (n0 + wn * 64 + j * 16 + col_in >= p.N) continue;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) out[(int64_t)(i * 16 + e) * p.ldn + j * 16] = acc[i][j][e];
+  }
+}
+
 int wgrad_splits(int M, int N, int P, int terms) {
   const int nk = P / (terms == 3 ? 32 : 64);
   const int s = wgrad_nominal_splits(M, N);
@@ -196,9 +306,20 @@ hipError_t launch_gemm_tn(const GemmTnParams& p, int terms, hipStream_t s) {
     return hipErrorInvalidValue;
   const int ntiles = (p.M / 256) * ((p.N + 255) / 256);
   const dim3 grid((unsigned)(ntiles * p.splits));
-  if (p.fmt == FMT_FP16) hipLaunchKernelGGL((k_gemm_tn<1, 1>), grid, dim3(512), 0, s, p);
-  else if (terms == 3) hipLaunchKernelGGL((k_gemm_tn<3, 0>), grid, dim3(512), 0, s, p);
-  else hipLaunchKernelGGL((k_gemm_tn<1, 0>), grid, dim3(512), 0, s, p);
+  // MFMA shape per operand format, from interleaved A/B runs of the training step: fp16 keeps
+  // 32 x 32 x 16 (the 16 x 16 x 32 form is 5 % slower on its own and in the step); the split formats -- three MFMAs
+  // per product, one k32-step per K-tile -- take 16 x 16 x 32.  LIST_TN_SHAPE=16 / 32 forces one (A/B runs).
+  static const int forced = [] { const char* e = getenv("LIST_TN_SHAPE"); return e ? atoi(e) : 0; }();
+  const bool shape32 = forced == 32 || (forced != 16 && p.fmt == FMT_FP16);
+  if (shape32) {
+    if (p.fmt == FMT_FP16) hipLaunchKernelGGL((k_gemm_tn<1, 1>), grid, dim3(512), 0, s, p);
+    else if (terms == 3) hipLaunchKernelGGL((k_gemm_tn<3, 0>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((k_gemm_tn<1, 0>), grid, dim3(512), 0, s, p);
+  } else {
+    if (p.fmt == FMT_FP16) hipLaunchKernelGGL((k_gemm_tn16<1, 1>), grid, dim3(512), 0, s, p);
+    else if (terms == 3) hipLaunchKernelGGL((k_gemm_tn16<3, 0>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((k_gemm_tn16<1, 0>), grid, dim3(512), 0, s, p);
+  }
   return hipGetLastError();
 }
 
