@@ -384,7 +384,7 @@ def run_train_step(precision, steps, warmup, inp, hip, ev):
     # bytes the three direct (global-atomic) voxel levels add: 56 taps x C channels per point, fp32 -- the 64^3 x 32 level
     # as packed halfs with fp16 operands; the window levels' flushes and the gathered 32^3 level come on top
     direct = P * 56 * (1 * 4 + 16 * 4 + 32 * (2 if precision == "fp16" else 4))
-    roofline = {"kernel": {"dgrad_fc0": "k_gemm_nt_pp / k_gemm_nt16 (dX = dZ1 . W0)", "wgrad_fc0": "k_gemm_tn (dW0 = dZ1^T . X)"}[dom],
+    roofline = {"kernel": {"dgrad_fc0": "k_gemm_nt_pp / k_gemm_nt16 (dX = dZ1 . W0)", "wgrad_fc0": ("k_gemm_tn" if precision == "fp16" else "k_gemm_tn16") + " (dW0 = dZ1^T . X)"}[dom],   # shape per format
                 "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                 "traffic": None, "launch_ms": inline_ms[dom], "algorithmic_flop_per_launch": flop0,
                 "mfma_products_per_mac": products, "timed": "in line on one stream, 3 untimed steps (stage events)",
