@@ -88,8 +88,17 @@ __device__ __forceinline__ s16x8 cat4(const s16x4& lo, const s16x4& hi) {
 }
 
 // grid = splits * tiles; workgroup 256 x 256 outputs, 8 waves as 2 (M) x 4 (N), wave 128 x 64.
+//
+// Register cap (round 3).  Left to itself the compiler spends the whole budget of two waves per SIMD (250 of 256
+// registers, most of them on hoisted fragment reads), and two such waves own the SIMD's 512 registers: no wave of
+// another kernel is ever resident beside a weight-gradient workgroup.  In the forked backward dW0 runs beside the
+// voxel scatters and the map-side gathers for most of their time (list_capi.hip), kernels of 16 - 40 registers per
+// wave that wait on memory: capped at 194 registers (no scratch; the kernel itself is not slower, 0.78 ms) two of its
+// waves leave room for four of theirs per SIMD, and the fp16 backward takes 4.50 instead of 4.73 ms.
+// amdgpu_num_vgpr counts ARCHITECTURAL registers on gfx90a and later -- the backend doubles it for the unified file --
+// so 112 caps the kernel at 224; the next lower values that compile (96 and below) spill.
 template <int TERMS, int FP16>
-__global__ __launch_bounds__(512, 2) void k_gemm_tn(GemmTnParams p) {
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(112))) void k_gemm_tn(GemmTnParams p) {
   using P = TnPipe<TERMS>;
   __shared__ __attribute__((aligned(16))) char smem[kTnLds];
   const int lane = threadIdx.x & 63;
@@ -306,11 +315,13 @@ hipError_t launch_gemm_tn(const GemmTnParams& p, int terms, hipStream_t s) {
     return hipErrorInvalidValue;
   const int ntiles = (p.M / 256) * ((p.N + 255) / 256);
   const dim3 grid((unsigned)(ntiles * p.splits));
-  // MFMA shape per operand format, from interleaved A/B runs of the training step: fp16 keeps
-  // 32 x 32 x 16 (the 16 x 16 x 32 form is 5 % slower on its own and in the step); the split formats -- three MFMAs
-  // per product, one k32-step per K-tile -- take 16 x 16 x 32.  LIST_TN_SHAPE=16 / 32 forces one (A/B runs).
+  // MFMA shape per operand format, from interleaved A/B runs of the training step: the
+  // single-plane formats keep 32 x 32 x 16 (k_gemm_tn: 194 registers under its cap; the 16 x 16 x 32 form needs 246, is
+  // 5 % slower on its own and leaves no room beside it); the split formats -- three MFMAs per product, one k32-step per
+  // K-tile -- take 16 x 16 x 32 (212 registers; 0.1 ms ahead of the capped 32 x 32 x 16 form in the bf16x3 step).
+  // LIST_TN_SHAPE=16 / 32 forces one (A/B runs).
   static const int forced = [] { const char* e = getenv("LIST_TN_SHAPE"); return e ? atoi(e) : 0; }();
-  const bool shape32 = forced == 32 || (forced != 16 && p.fmt == FMT_FP16);
+  const bool shape32 = forced == 32 || (forced != 16 && terms != 3);
   if (shape32) {
     if (p.fmt == FMT_FP16) hipLaunchKernelGGL((k_gemm_tn<1, 1>), grid, dim3(512), 0, s, p);
     else if (terms == 3) hipLaunchKernelGGL((k_gemm_tn<3, 0>), grid, dim3(512), 0, s, p);

@@ -62,7 +62,10 @@ __device__ __forceinline__ void scatter_direct(const ScatterParams& sp, const Li
 // limit).  Beside other kernels (ListQueryGradArgs.aux_streams) a small grid is better for the whole: the
 // atomics of a CU fill its vector-memory queue, and every load of a neighbouring gather kernel waits behind
 // them (backward 5.92 ms with 512 workgroups, 5.57 ms with 128).
-constexpr int kDirectGrid = 512, kDirectGridForked = 128;
+#ifndef LIST_DIRECT_GRID_FORKED
+#define LIST_DIRECT_GRID_FORKED 128      // (re-measured in round 3 with dW0 capped at 194 registers: DESIGN 5b)
+#endif
+constexpr int kDirectGrid = 512, kDirectGridForked = LIST_DIRECT_GRID_FORKED;
 
 template <int C, int DXH>
 __global__ __launch_bounds__(256) void k_scatter_vox(ScatterParams sp, ListVoxLevel gv, int col_off, int nblocks) {
