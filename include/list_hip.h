@@ -200,7 +200,7 @@ typedef struct ListQueryArgs {
                                         /*   operands, H2 = H3 = 256; other cases: no effect).  The  */
                                         /*   values are those of the two-launch path bit for bit     */
                                         /*   (same products, k order and summation tree).  0         */
-                                        /*   (default): H1 and H2 are left in the workspace for the  */
+                                        /*   (default): H1, H2, H3 are left in the workspace for the */
                                         /*   backward.  list_sdf_query_bwd refuses (LIST_ERR_ARG) a  */
                                         /*   forward that had it set.                                */
 } ListQueryArgs;

@@ -580,6 +580,21 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4v (&ac
         v += __shfl_xor(v, 1);
         part[i][e] = v;
       }
+    if (p.out_hi) {
+      // a forward that keeps its activations: H3 = relu(fc_2) leaves as 16-bit planes like H1 / H2 (the backward's
+      // head takes its ReLU mask, dZ3 and d fc_out.weight from it; until round 3 it re-ran this product for them).
+      // Same values the dot product above used; the staged helper brackets its LDS turns with barriers.
+      const int64_t row_base = m0 + wm * 128;
+      const int col_base = wn * 64;                    // n0 == 0 (N == BN)
+      staged_epilogue16(acc, smem, wave, lane, [&](int r, int c8, const float (&v)[8]) {
+        const float4 b0 = *(const float4*)(p.bias + col_base + c8), b1 = *(const float4*)(p.bias + col_base + c8 + 4);
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = relu_nan(v[e] + bb[e]);
+        store8_planes<FP16>(p.out_hi, p.out_lo, (row_base + r) * p.ldo + col_base + c8, o);
+      });
+    }
     __syncthreads();
     float* red = (float*)smem;                         // [4 (wn)][256 rows]
     if (col_in == 0) {

@@ -482,7 +482,10 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
     gp.w_hi = wp + pk.w2_hi; gp.w_lo = wp + pk.w2_lo;
     gp.bias = (const float*)(wp + pk.b2);
     gp.N = a->H3; gp.K = a->H2;
-    gp.out_hi = nullptr; gp.out_lo = nullptr;
+    // H3 is kept with H1 / H2 for list_sdf_query_bwd (its head needs relu(fc_2): mask, dZ3, d fc_out.weight)
+    gp.out_hi = (unsigned short*)(wsb + ws.h3_hi);
+    gp.out_lo = terms == 3 ? (unsigned short*)(wsb + ws.h3_lo) : nullptr;
+    gp.ldo = a->H3;
     gp.w3 = (const float*)(wp + pk.w3); gp.b3 = (const float*)(wp + pk.b3);
     gp.sdf = a->sdf + p0; gp.n_valid = n_valid; gp.order = g.order;
     e = launch_gemm(gp, terms, EPI_RELU_DOT, s);
@@ -718,8 +721,10 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   const ScatterStreams sst = {s, s_direct, s_window};
 
   mark(LIST_BWD_BEGIN);
-  // --- head: scale, fc_2 re-evaluation (H3), dZ3, d fc_out ----------------------------------------------
+  // --- head: scale, dZ3, d fc_out (H3 = relu(fc_2) as the forward left it in its workspace) -------------------
   LIST_TRY(launch_grad_scale(ga->grad_sdf, P, fp16 ? 1 : 0, scale, ga->mlp.b3, colsum, s), "grad_scale launch");
+#ifdef LIST_BWD_REEVAL_FC2
+  // (until round 3, kept for A/B builds: the forward's fused fc_2 + fc_out epilogue wrote no H3, so fc_2 ran again here)
   GemmParams gp;
   memset(&gp, 0, sizeof(gp));
   gp.fmt = fmt;
@@ -729,11 +734,16 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   gp.M = crow; gp.N = a->H3; gp.K = a->H2;
   gp.out_hi = plane(bw.h3_hi); gp.out_lo = lo ? plane(bw.h3_lo) : nullptr; gp.ldo = a->H3;
   LIST_TRY(launch_gemm(gp, terms, EPI_RELU_SPLIT, s), "fc_2 re-evaluation launch");
-  LIST_TRY(launch_head(ga->grad_sdf, order, n_valid, crow, a->H3, plane(bw.h3_hi), (const float*)(wp + pk.w3),
+  unsigned short* const h3_hi = plane(bw.h3_hi);
+  unsigned short* const h3_lo = lo ? plane(bw.h3_lo) : nullptr;
+#else
+  unsigned short* const h3_hi = (unsigned short*)(fw + ws.h3_hi);
+  unsigned short* const h3_lo = lo ? (unsigned short*)(fw + ws.h3_lo) : nullptr;
+#endif
+  LIST_TRY(launch_head(ga->grad_sdf, order, n_valid, crow, a->H3, h3_hi, (const float*)(wp + pk.w3),
                        scale, plane(bw.dz3_hi), lo ? plane(bw.dz3_lo) : nullptr, fmt, s), "head launch");
   if (ga->mlp.w3)
-    LIST_TRY(side_colsum(plane(bw.h3_hi), lo ? plane(bw.h3_lo) : nullptr, a->H3, ga->grad_sdf, order, 0, ga->mlp.w3),
-             "d fc_out.weight launch");
+    LIST_TRY(side_colsum(h3_hi, h3_lo, a->H3, ga->grad_sdf, order, 0, ga->mlp.w3), "d fc_out.weight launch");
   if (ga->mlp.b2)
     LIST_TRY(side_colsum(plane(bw.dz3_hi), lo ? plane(bw.dz3_lo) : nullptr, a->H3, nullptr, nullptr, 1, ga->mlp.b2),
              "d fc_2.bias launch");

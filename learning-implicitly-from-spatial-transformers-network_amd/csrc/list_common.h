@@ -341,15 +341,18 @@ constexpr int kSortImages = 64;                              // image slots in t
 constexpr int kSortPixCells = 8192;                          // pixel-order bins per image (>= ms * ceil(ms/4))
 constexpr int kSortBins = (kSortCells + kSortPixCells) * kSortImages;   // Morton + pixel counters (3 MB)
 
+constexpr int kH3 = 256;                             // fc_2's width: the C API accepts no other (list_capi.hip)
 struct Workspace {
   size_t x_hi, x_lo, h1_hi, h1_lo, h2_hi, h2_lo;     // byte offsets
+  size_t h3_hi, h3_lo;                               // fc_2 activations of a forward that keeps them (round 3: the
+                                                     //   backward's head read a re-evaluation of fc_2 before)
   size_t order, keys, bins;                          // point sort: int32 [rows], [rows], [kSortBins]
   size_t order_img, row_of, keys2;                   // pixel order for the 2-D gather; point -> X row
   size_t nan_tiles;                                  // int32 [rows / 256]: tiles whose fc_0 output holds a NaN
   size_t total;
 };
 inline size_t workspace_row_bytes(int Kp, int H1, int H2) {
-  return (size_t)2 * 2 * ((size_t)Kp + H1 + H2) + 21;
+  return (size_t)2 * 2 * ((size_t)Kp + H1 + H2 + kH3) + 21;
 }
 inline size_t workspace_fixed_bytes() { return (size_t)kSortBins * 4 + 17 * 256; }
 inline Workspace workspace_layout(int64_t rows, int Kp, int H1, int H2) {
@@ -359,6 +362,7 @@ inline Workspace workspace_layout(int64_t rows, int Kp, int H1, int H2) {
   w.x_hi = take((size_t)rows * Kp * 2); w.x_lo = take((size_t)rows * Kp * 2);
   w.h1_hi = take((size_t)rows * H1 * 2); w.h1_lo = take((size_t)rows * H1 * 2);
   w.h2_hi = take((size_t)rows * H2 * 2); w.h2_lo = take((size_t)rows * H2 * 2);
+  w.h3_hi = take((size_t)rows * kH3 * 2); w.h3_lo = take((size_t)rows * kH3 * 2);
   w.order = take((size_t)rows * 4); w.keys = take((size_t)rows * 4);
   w.order_img = take((size_t)rows * 4); w.row_of = take((size_t)rows * 4);
   w.keys2 = take((size_t)rows * 4);
