@@ -54,3 +54,25 @@ def test_pmc_traffic_belongs_to_the_batch_it_was_collected_on():
     got = bench.pmc_traffic("fp16", METRIC, B)
     # (empty as well when profiles/pmc_traffic.json is older than the kernel sources: stale counters are dropped)
     assert got == {} or "fc_0" in got
+
+
+def test_profile_summaries_name_kernels_that_rocprof_left_mangled():
+    """rocprofv3 does not demangle signatures with `_Float16*` parameters (PDF16_): the LDS-window and packed-half
+    scatter kernels of the backward.  A summary keyed on demangled names filed them under "other: torch / rocclr"
+    (60 ms of one trace) until round 3; both tools now read the mangled form as well."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import pmc_traffic
+    import summarize_prof as sp
+    assert sp.short('"_ZN4list17k_scatter_vox_winILi128ELi1ELi18432EEEvNS_13ScatterParamsE12ListVoxLeveliPDF16_"') \
+        == "k_scatter_vox_win<128, 1, 18432>"
+    assert sp.short("_ZN4list16k_scatter_vox_h2ILi32EEEvNS_13ScatterParamsE12ListVoxLeveliiPDF16_") == "k_scatter_vox_h2<32>"
+    assert sp.short("_ZN4list13k_h16_to_gradEPKDF16_PflPKff") == "k_h16_to_grad"
+    # the two spellings of one kernel agree, bools included
+    assert sp.short("void list::k_gemm_nt_pp<0, 1, true, 0>(list::GemmParams)") == "k_gemm_nt_pp<0, 1, true, 0>"
+    assert sp.short("_ZN4list12k_gemm_nt_ppILi0ELi1ELb1ELi0EEEvNS_10GemmParamsE") == "k_gemm_nt_pp<0, 1, true, 0>"
+    # kernels of other libraries stay anonymous
+    assert sp.short("void at::native::vectorized_elementwise_kernel<4, foo>(int)") is None
+    assert sp.short("_ZN2at6native3fooEv") is None
+    assert pmc_traffic.kernel_key("_ZN4list14k_mlp_tail_f16ENS_10TailParamsE", 320000, 0) == "fc_2_out"
+    assert pmc_traffic.kernel_key("void list::k_gemm_nt_pp<0, 1, true, 0>(list::GemmParams)", 640000, 0) == "fc_0"
+

@@ -17,11 +17,15 @@ import re
 import sys
 from collections import defaultdict
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from summarize_prof import short  # noqa: E402
+
 csv.field_size_limit(1 << 30)
 
 
 def kernel_key(name, grid, seq):
-    m = re.search(r"list::(k_[a-z_0-9]+)(<[^>]*>)?", name)
+    # (demangled `list::k_...<...>` or, where rocprofv3 left the name mangled, the same form rebuilt from it)
+    m = re.match(r"(k_[a-z_0-9]+)(<[^>]*>)?", short(name) or "")
     if not m:
         return None
     k, t = m.group(1), (m.group(2) or "")

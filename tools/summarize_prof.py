@@ -15,10 +15,35 @@ from collections import defaultdict
 csv.field_size_limit(1 << 30)
 
 
+def _mangled(name):
+    """`_ZN4list<len><kernel>[I<template args>E]...` -> 'k_name<a, b, ...>' (integer and bool arguments), or None.
+    rocprofv3 leaves a name mangled when its demangler does not know a parameter type (`_Float16*` = PDF16_: the
+    LDS-window and packed-half scatter kernels of the backward), and a summary keyed on demangled names only would
+    silently file those kernels under "other"."""
+    m = re.match(r"_ZN4list(\d+)", name)
+    if not m:
+        return None
+    n, i = int(m.group(1)), m.end()
+    kernel, i = name[i:i + n], i + n
+    if not re.fullmatch(r"k_[a-z_0-9]+", kernel):
+        return None
+    args = []
+    if name[i:i + 1] == "I":
+        i += 1
+        while i < len(name) and name[i] != "E":
+            a = re.match(r"L([a-z])(n?)(\d+)E", name[i:])
+            if not a:
+                return kernel + "<?>"
+            v = ("-" if a.group(2) else "") + a.group(3)
+            args.append({"0": "false", "1": "true"}[a.group(3)] if a.group(1) == "b" else v)
+            i += a.end()
+    return kernel + (f"<{', '.join(args)}>" if args else "")
+
+
 def short(name):
     name = name.strip('"')
     m = re.search(r"list::(k_[a-z_0-9]+)(<[^>]*>)?", name)
-    return (m.group(1) + (m.group(2) or "")) if m else None
+    return (m.group(1) + (m.group(2) or "")) if m else _mangled(name)
 
 
 def kernel_trace(d):
