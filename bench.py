@@ -27,6 +27,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 W_FLOP_PER_PT = 2 * (3610 * 512 + 512 * 256 + 256 * 256 + 256)      # 4 090 368
+def P_FLOP_FC0(points):              # algorithmic FLOP of one fc_0 launch (K = 3610, not the padded K)
+    return points * 2 * 3610 * 512
 W_BYTE_PER_PT = (7 * 8 * 369 + 4 * 1024) * 4 + 16                     # 99 056 fp32 maps
 DETAIL_STEPS = 3                 # untimed steps that time each gather on its own (run_config)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
@@ -148,8 +150,23 @@ def kernel_table(B, N, img_res, vox_res, map_size, x_bytes_per_feature, map_byte
     return t
 
 
+# LIST_BENCH_FORCE_EXCHANGE=1: a ONE-rank process group takes the N > 1 code path (process group, exchange buffers,
+# asynchronous all-gather, exchange check, rank census): the RCCL pre-flight on a one-GPU box
+# (tests/test_rccl_preflight_gpu.py, with LIST_FORCE_COLLECTIVES=1 for list_amd.parallel).  Never a scaling number.
+FORCE_EXCHANGE = os.environ.get("LIST_BENCH_FORCE_EXCHANGE", "0") == "1"
+PREP_FORK = os.environ.get("LIST_BENCH_PREP_FORK", "0") != "0"
+_side = {}
+def _side_stream(device):
+    import torch
+    if device not in _side:
+        _side[device] = torch.cuda.Stream(device)
+    return _side[device]
+
+
 def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gather_fn, sustained_steps=0):
+    import torch
     import torch.distributed as dist
+    multi = world > 1 or FORCE_EXCHANGE
     B, N = inp["B"], inp["N"]
     n_ev = hip.N_STAGES
     # one event set per row chunk of the call (ListQueryArgs.stage_event_sets): the intervals of all chunks are
@@ -172,12 +189,14 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
     # (strong scaling: the global batch may not divide by the ranks -- every rank exchanges a buffer of B_pad =
     # ceil(B_global / world) images, of which it fills its own B)
     B_pad = inp.get("B_pad", B)
-    gathered = [torch.empty((world * B_pad, N), dtype=torch.float32, device=device) for _ in range(2)] if world > 1 else None
-    sdf_bufs = [torch.zeros((B_pad, N), dtype=torch.float32, device=device) for _ in range(2 if world > 1 else 1)]
+    gathered = [torch.empty((world * B_pad, N), dtype=torch.float32, device=device) for _ in range(2)] if multi else None
+    sdf_bufs = [torch.zeros((B_pad, N), dtype=torch.float32, device=device) for _ in range(2 if multi else 1)]
     sdfs = [b[:B] for b in sdf_bufs]
     pending = [None, None]
     n_calls = [0]
     overlap_exchange = [True]
+
+    plan = {}                    # what the library dispatched for the step's query (list_query_plan)
 
     def step(events=None):
         pre, arr = events if events else (None, None)
@@ -189,10 +208,21 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
             pending[k] = None
         if pre: ev.record(pre[0])
         md = hip.map_dtype_for(precision)
-        img = hip.prep_img_maps(inp["img_maps"], inp["map_size"], md)
-        if pre: ev.record(pre[1])
-        vox = hip.prep_vox_maps(inp["vox_maps"], md)
-        if pre: ev.record(pre[2])
+        if PREP_FORK:
+            # EXPERIMENT (round 4): the resize of the 2-D maps on a side stream beside the 3-D layout hand-off
+            cur = torch.cuda.current_stream()
+            side = _side_stream(device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                img = hip.prep_img_maps(inp["img_maps"], inp["map_size"], md)
+            vox = hip.prep_vox_maps(inp["vox_maps"], md)
+            cur.wait_stream(side)
+            if pre: ev.record(pre[1]); ev.record(pre[2])
+        else:
+            img = hip.prep_img_maps(inp["img_maps"], inp["map_size"], md)
+            if pre: ev.record(pre[1])
+            vox = hip.prep_vox_maps(inp["vox_maps"], md)
+            if pre: ev.record(pre[2])
         packed = hip.prep_mlp_weights(inp["weights"], vox.channels, img.channels, precision)
         # inference grid (executors.LIST.predict_grid): many points on one image -- the perceptual block of fc_0 is
         # applied to the 137^2 map once (inside the timed step, counted with prep_weights) and sampled per point
@@ -200,8 +230,8 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
         if pre: ev.record(pre[3])
         hip.sdf_query(inp["query"], inp["trans_mat"], img, vox, packed, precision=precision,
                       out=sdf, stage_events=arr, clamp_hi=inp["clamp_hi"],
-                      sort_points=not inp.get("ordered_points", False), percep_proj=proj)
-        if world > 1:
+                      sort_points=not inp.get("ordered_points", False), percep_proj=proj, plan=plan)
+        if multi:
             if overlap_exchange[0]:
                 try:
                     _, pending[k] = gather_fn(sdf_bufs[k], out=gathered[k], async_op=True)
@@ -223,7 +253,7 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
         step()
     drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -231,11 +261,11 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
         step(step_events[i])
     drain()                                   # every exchange has completed inside the timed region
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64,
                          device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -267,8 +297,11 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
             for s in range(first, hip.STAGE_IMG + 1):
                 acc[3 + s] += interval(arr, c, s, s + 1) / DETAIL_STEPS
     kernel_ms = dict(zip(names, acc.tolist()))
-    if precision == "fp16" and hip.keeps_no_activations():
-        # one launch for fc_1 + fc_2 + fc_out: the fc_1 interval holds two event records and no kernel
+    assert plan["chunks"] == n_chunks, (plan, n_chunks)
+    if plan["fused_tail"]:
+        # one launch for fc_1 + fc_2 + fc_out (as the LIBRARY dispatched it, list_query_plan -- not re-derived from the
+        # precision and the environment): the fc_1 interval holds two event records and no kernel
+        assert kernel_ms["fc_1"] < 0.02, kernel_ms["fc_1"]
         kernel_ms["fc_2_out"] += kernel_ms["fc_1"]
         kernel_ms["fc_1"] = 0.0
         kernel_ms["_fused_tail"] = 1
@@ -279,7 +312,7 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
     step_ms = sorted(ev.elapsed_ms(pre[0], pre[4]) for pre, _ in step_events)
     q = lambda f: step_ms[min(len(step_ms) - 1, int(f * len(step_ms)))]
     extra = {"elapsed_local_s": elapsed_local}
-    if world > 1:
+    if multi:
         # once, outside the timed region: what the exchange delivered holds this rank's shard at this rank's offset, and
         # every other rank's rows are finite numbers (not the zeros the buffer was born with)
         rank = dist.get_rank()
@@ -528,6 +561,22 @@ def path_roofs(value, precision, grid=False):
     return r
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run as a child process (the
+    driver's own N > 1 command line), pass its output through and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                       # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    print("bench: no launcher in the environment, starting " + " ".join(cmd), file=sys.stderr)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -550,33 +599,58 @@ def main():
     ap.add_argument("--cpu-sample-images", type=int, default=8,
                     help="images of the CPU baseline sample (default: the whole batch of the metric workload -- the 2-image sample "
                          "of rounds 1-2 read 1.8x low, profiles/r03_cpu_baseline_8_images.json)")
+    ap.add_argument("--plumbing-check", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-sample-points", type=int, default=50000,
                     help="points per image of the CPU baseline sample (bounds the 256^3 grid workload)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started the way the driver starts the N = 1 case (`python bench.py --gpus N`, no launcher): this process
+        # becomes the launcher.  Nothing has touched the GPU yet (importing torch does not), the ranks are CHILD
+        # processes (never an exec), and rank 0's JSON line and the launcher's return code are relayed.
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
         args.gpus = world
     import torch.distributed as dist
+    multi = world > 1 or FORCE_EXCHANGE
+    if args.plumbing_check:
+        # tests/test_bench_launch.py (CPU, gloo): launcher -> ranks -> rendezvous -> one collective -> rank 0's line,
+        # without a GPU: the argument and environment plumbing of the N > 1 start, nothing else
+        if os.environ.get("LIST_BENCH_PLUMBING_FAIL_RANK") == str(rank):
+            raise SystemExit(3)                        # (the test of the launcher's exit code)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        seen = [None] * world
+        dist.all_gather_object(seen, {"rank": rank, "local_rank": local_rank, "steps": args.steps, "warmup": args.warmup})
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"plumbing_check": True, "n_gpus": world, "ranks": seen, "scaling": args.scaling,
+                              "workload": args.workload}))
+        dist.destroy_process_group()
+        return
     # LIST_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the control flow of the
     # N > 1 path on a single-GPU box (RCCL refuses duplicate devices); the driver uses nccl (= RCCL).
     backend = os.environ.get("LIST_BENCH_BACKEND", "nccl")
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:            # (a one-rank group started without a launcher: the pre-flight)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     import __graft_entry__ as ge
-    if world > 1:                       # one builder per node, the others wait for the library
+    if multi:                       # one builder per node, the others wait for the library
         if local_rank == 0:
             ge.build()
         dist.barrier()
@@ -639,6 +713,17 @@ def main():
                "ms_per_step": a_el / a_steps * 1e3, "kernel_ms": a_ms,
                "max_abs_diff_vs_headline": float((a_sdf - sdf).abs().max())}
 
+    alt_bf16 = None
+    if args.precision is None and "bf16" not in (headline, alt_prec):
+        # BASELINE config 2 says "bf16": the plain-bf16 mode (one MFMA product per MAC on bf16 operands, fp32 maps) as
+        # a third first-class mode of the line, with its stated tolerance (5e-3 absolute) and both parity legs below
+        b_steps = max(2, args.steps // 2)
+        b_el, b_ms, b_sdf, _ = run_config(args, "bf16", b_steps, min(args.warmup, 2), inp, hip, ev, world, device, gather_fn)
+        alt_bf16 = {"precision": "bf16", "value": global_points * b_steps / b_el, "steps": b_steps,
+                    "ms_per_step": b_el / b_steps * 1e3, "fc_0_ms": b_ms["fc_0"],
+                    "roofline_frac": P_FLOP_FC0(B * N) / (b_ms["fc_0"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                    "max_abs_diff_vs_headline": float((b_sdf - sdf).abs().max())}
+
     train = None
     train_grads = None
     if args.precision is None and not args.no_train_step and B * N <= 262144:
@@ -657,7 +742,7 @@ def main():
         whole = run_whole_model(args.workload, headline, device)
 
     ranks = None
-    if world > 1:
+    if multi:
         # what the collective backend really spans: every rank's id and timed-region wall clock through an all-gather
         # round trip (nccl = RCCL on device tensors; the gloo rehearsal stages through the host)
         on = device if dist.get_backend() == "nccl" else "cpu"
@@ -673,7 +758,7 @@ def main():
                  "exchange_check": extra.get("exchange_check")}
 
     if rank != 0:
-        if world > 1:
+        if multi:
             dist.destroy_process_group()
         return
 
@@ -733,7 +818,7 @@ def main():
     parity = None
     parity_leg = None
     modes = {}
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and not multi:
         from oracle import torch_ops as TO
         ns = min(args.cpu_sample_images, B)
         cq = inp["query"][:ns].cpu()
@@ -778,7 +863,7 @@ def main():
             ref_big = TO.list_query(cq, ci, cv, ct, {k: v.cpu() for k, v in big_w.items()}, **kw)
             tolerance = TOLERANCE
             modes = {}
-            for prec in dict.fromkeys([headline, alt_prec] if args.precision is None else [headline]):
+            for prec in dict.fromkeys([headline, alt_prec, "bf16"] if args.precision is None else [headline]):
                 legs = {"bench_distribution": leg(forward(prec, inp["weights"]), ref),
                         "sdf_about_0.5": leg(forward(prec, big_w), ref_big)}
                 tol = tolerance[prec]
@@ -812,6 +897,9 @@ def main():
     if alt is not None:
         perf[alt["precision"]] = {"value": alt["value"], "ms_per_step": alt["ms_per_step"],
                                   "roofline_frac": alt["roofline"]["frac"]}
+    if alt_bf16 is not None:
+        perf["bf16"] = {"value": alt_bf16["value"], "ms_per_step": alt_bf16["ms_per_step"],
+                        "roofline_frac": alt_bf16["roofline_frac"]}
     for prec, pf in perf.items():
         modes.setdefault(prec, {"stated_tolerance": TOLERANCE[prec], "parity_vs_cpu": None}).update(pf)
     arith = {"bf16x3": "bf16 hi/lo split operands, 3 MFMA products per MAC, fp32 accumulate",
@@ -842,7 +930,7 @@ def main():
                    # names the collective that RAN: RCCL on the "nccl" backend, gloo in the one-GPU rehearsals
                    "parallelism": f"batch-sharded x{world}" + (
                        (" + RCCL all-gather of sdf" if dist.get_backend() == "nccl" else
-                        f" + {dist.get_backend()} all-gather of sdf (rehearsal, not RCCL)") if world > 1 else "")},
+                        f" + {dist.get_backend()} all-gather of sdf (rehearsal, not RCCL)") if multi else "")},
         "ranks": ranks,
         "step_events_ms": extra["step_events_ms"],
         "sustained": extra.get("sustained"),
@@ -864,12 +952,34 @@ def main():
         "modes": modes,
         "speedup_vs_cpu": (value / cpu["value"]) if cpu else None,
         "alt": alt,
+        "alt_bf16": alt_bf16,
         "alt_channels_last_inputs": alt_cl,
         "train_step": train,
         "whole_model": whole,
     }
+    # the LAST object of the line: what a reviewer needs, short enough for a 2 000-character tail of the output
+    # (Mpts = million query-points/s; err = max|sdf - CPU reference| on the benched distribution / at |sdf| ~ 0.5)
+    def _mode(pr):
+        m = modes.get(pr)
+        if not m or "value" not in m:
+            return None
+        pv = m.get("parity_vs_cpu")
+        errs = [float(f"{pv[k]['max_abs_err']:.1e}") for k in ("bench_distribution", "sdf_about_0.5")] if pv else None
+        return {"Mpts": round(m["value"] / 1e6, 2), "ms": round(m["ms_per_step"], 3), "err": errs}
+    out["summary"] = {
+        "fp16": _mode("fp16"), "bf16x3": _mode("bf16x3"), "bf16": _mode("bf16"),
+        "channels_last_Mpts": round(alt_cl["value"] / 1e6, 2) if alt_cl else None,
+        "train_ms": [round(train["ms_per_step"], 2), round(train["fp32_grade"]["ms_per_step"], 2)] if train else None,
+        "bwd_ms": [round(train["backward_ms"], 2), round(train["fp32_grade"]["backward_ms"], 2)] if train else None,
+        "fc0_ms": round(kernel_ms["fc_0"], 4), "fc0_frac": round(roof["frac"], 3),
+        "gathers_ms": round(gather_ms, 4), "prep_ms": round(kernel_ms["prep_img_resize_nhwc"] + kernel_ms["prep_vox_ndhwc"], 4),
+        "path_frac": round(path["whole_path_frac_of_binding_roof"], 3),
+        "hbm_GB_step": round(path["hbm_bytes_per_step_pmc"] / 1e9, 2) if "hbm_bytes_per_step_pmc" in path else None,
+        "cpu_kpts": round(cpu["value"] / 1e3, 1) if cpu else None, "cpu_cores": cpu["cores"] if cpu else None,
+    }
+    assert len(json.dumps(out["summary"])) <= 700, len(json.dumps(out["summary"]))
     print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

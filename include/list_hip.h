@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LIST_ABI_VERSION 6
+#define LIST_ABI_VERSION 7
 
 #define LIST_N_IMG_LEVELS 5   /* ResEncoder feature maps, network/modules.py:1067 */
 #define LIST_N_VOX_LEVELS 6   /* VoxelEncoder2 feature maps, network/modules.py:425-442 */
@@ -238,6 +238,22 @@ size_t list_query_workspace_bytes(int64_t n_points, int32_t F, int32_t H1, int32
 int64_t list_query_chunk_rows(size_t workspace_bytes, int64_t n_points, int32_t F, int32_t H1, int32_t H2,
                               int32_t H3);
 int list_sdf_query_fwd(const ListQueryArgs* args, void* stream);
+
+/* list_query_plan (ABI 7) -- what list_sdf_query_fwd WOULD dispatch for `args` (validated like the call itself; no
+ * launch, no HIP call): for callers that account per kernel (bench.py: which launch the fc_1 interval belongs to)
+ * instead of re-deriving the library's dispatch conditions from the arguments and the environment. */
+typedef struct ListQueryPlan {
+  int64_t rows_per_chunk;   /* = list_query_chunk_rows() for args->workspace_bytes */
+  int32_t chunks;           /* row chunks the call runs back to back */
+  int32_t fused_tail;       /* 1: fc_1 + fc_2 + fc_out run as ONE launch (no kernel between LIST_STAGE_EXACT and   */
+                            /*    LIST_STAGE_FC1), 0: two launches                                                   */
+  int32_t fc0_k;            /* K of the fc_0 launch (feature columns incl. padding, less the perceptual block when */
+                            /*    args->percep_proj is given)                                                      */
+  int32_t box_levels;       /* bit l: voxel level l is gathered on the matrix cores (k_gather_vox_box: a level whose  */
+                            /*    stencil stays inside one cell, 128 channels, fp16 maps and fp16 operands)           */
+  int32_t reserved_[2];
+} ListQueryPlan;
+int list_query_plan(const ListQueryArgs* args, ListQueryPlan* plan);
 
 /* ---------------------------------------------------------------------------------------
  * list_percep_pool_fwd -- PerceptualPooling.forward alone (network/modules.py:37-53) for

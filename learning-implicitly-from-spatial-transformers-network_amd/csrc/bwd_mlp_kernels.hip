@@ -95,8 +95,10 @@ __device__ __forceinline__ s16x8 cat4(const s16x4& lo, const s16x4& hi) {
 // voxel scatters and the map-side gathers for most of their time (list_capi.hip), kernels of 16 - 40 registers per
 // wave that wait on memory: capped at 194 registers (no scratch; the kernel itself is not slower, 0.78 ms) two of its
 // waves leave room for four of theirs per SIMD, and the fp16 backward takes 4.50 instead of 4.73 ms.
-// amdgpu_num_vgpr counts ARCHITECTURAL registers on gfx90a and later -- the backend doubles it for the unified file --
-// so 112 caps the kernel at 224; the next lower values that compile (96 and below) spill.
+// amdgpu_num_vgpr(112) is the LIMIT handed to the register allocator (architectural registers; the backend doubles it
+// for the unified file: at most 224); what the compiler then USES is 194, in all three instantiations the attribute
+// covers -- <1, 1> fp16, <1, 0> plain bf16, <3, 0> bf16x3 under LIST_TN_SHAPE=32 -- each with ScratchSize 0
+// (-Rpass-analysis=kernel-resource-usage, round 4).  The next lower limits that compile (96 and below) spill.
 template <int TERMS, int FP16>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(112))) void k_gemm_tn(GemmTnParams p) {
   using P = TnPipe<TERMS>;

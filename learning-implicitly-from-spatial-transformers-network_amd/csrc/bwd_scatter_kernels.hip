@@ -347,6 +347,7 @@ __global__ __launch_bounds__((C >= 128 ? C : 128)) void k_scatter_vox_win(Scatte
       for (int q = 0; q < 32; ++q) gs += Gacc[q];
       mine[0] += gs;
 #else
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // (pairs with the release behind the gro[] stores)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {                  // two batches of 16 (addresses are distinct within the 32, or the dummy)
         float v[16];
@@ -390,6 +391,10 @@ __global__ __launch_bounds__((C >= 128 ? C : 128)) void k_scatter_vox_win(Scatte
           if (cur_cell != -2) add_group();
           cur_cell = cell;
           if ((tid & 63) < 32) gro[tid & 31] = n.o[tid & 31];
+          // lanes 32..63 read offsets that lanes 0..31 stored: a wavefront-scope release here (and the acquire in
+          // add_group) keeps the compiler from reusing gro[] loads across the store (the hardware executes the DS
+          // operations of one wave in order; the fences cost no instruction beyond an lgkmcnt wait)
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
           for (int q = 0; q < 32; ++q) Gacc[q] = 0.f;
         }

@@ -450,6 +450,8 @@ __global__ __launch_bounds__(256) void k_gather_vox_box(GatherParams g, ListVoxL
                 *(uint4*)(tw + (col & 7) * RB + (((4 * u + q) ^ (col & 7)) << 4)) = make_uint4(lo.x, lo.y, hi.x, hi.y);
               }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // lanes read what other lanes of the wave stored
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) {
               const int r8 = 4 * k2 + (lane >> 4), chunk = lane & 15;

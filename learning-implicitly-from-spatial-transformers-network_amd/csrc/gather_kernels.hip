@@ -6,6 +6,8 @@
 //   * k_gather_tail    : scalar (C==1) voxel levels, xyz coordinates, zero padding
 // All write the bf16 hi/lo feature matrix X[row][Kp] in gather order (list_common.h).
 // Lanes run over channel quads (16-B loads, coalesced along C); a workgroup owns 64 points.
+#include <string.h>
+
 #include "list_common.h"
 #include "point_math.h"
 
@@ -98,14 +100,15 @@ __device__ __forceinline__ void reduce_taps_exact(const typename M::Raw (&v)[8],
 
 // store V consecutive features of one row of X.  V == 8 means the values were interpolated from fp16 maps and
 // cannot leave the fp16 range: no saturation step (half4_inrange)
-template <int FMT, int V>
+template <int FMT, int V, bool NT = false>
 __device__ __forceinline__ void store_feats(unsigned short* __restrict__ xh, unsigned short* __restrict__ xl,
                                             int64_t off, const float (&a)[V], bool valid) {
   if constexpr (FMT == FMT_FP16 && V == 8) {       // 8 halfs: one 16-B store
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     const uint2 lo = half4_inrange(valid ? make_float4(a[0], a[1], a[2], a[3]) : make_float4(0.f, 0.f, 0.f, 0.f));
     const uint2 hi = half4_inrange(valid ? make_float4(a[4], a[5], a[6], a[7]) : make_float4(0.f, 0.f, 0.f, 0.f));
-    x_store<true>((u32x4){lo.x, lo.y, hi.x, hi.y}, (u32x4*)(xh + off));
+    if constexpr (NT) __builtin_nontemporal_store((u32x4){lo.x, lo.y, hi.x, hi.y}, (u32x4*)(xh + off));
+    else x_store<true>((u32x4){lo.x, lo.y, hi.x, hi.y}, (u32x4*)(xh + off));
     return;
   }
 #pragma unroll
@@ -562,7 +565,14 @@ __global__ __launch_bounds__(256) void k_gather_img(GatherParams g, const void* 
         }
         tap_mul<M>(v[k][0], a.pr.w00, r); tap_fma<M>(v[k][1], a.pr.w01, r);
         tap_fma<M>(v[k][2], a.pr.w10, r); tap_fma<M>(v[k][3], a.pr.w11, r);
+        // the perceptual block of a row is 2 KB of whole, line-aligned lines written once: non-temporal (round 4, two
+        // interleaved pairs on one device: this kernel 0.244 -> 0.235 ms, gather group 0.850 -> 0.828, step -0.02 ms;
+        // the 32 ... 256-B pieces of the voxel gathers keep the plain stores that merge in L2, list_common.h x_store)
+#ifdef LIST_IMG_PLAIN_STORES
         store_feats<FMT, M::V>(xh, xl, (int64_t)a.row * g.Kp + col_off + q * M::V, r, a.valid != 0);
+#else
+        store_feats<FMT, M::V, true>(xh, xl, (int64_t)a.row * g.Kp + col_off + q * M::V, r, a.valid != 0);
+#endif
       }
     }
   }
@@ -850,6 +860,55 @@ static hipError_t launch_gather_fmt(const GatherParams& g, const FeatLayout& L, 
   // one device (tools/ab_gather.sh): with the coarse levels LAST the group takes 0.79-0.83 instead of 0.85-0.87 ms and
   // fc_0 behind it 0.50-0.53 instead of 0.48 ms -- group + fc_0 = 1.34-1.35 ms whatever the order (the X lines the
   // gathers leave dirty in the L2s drain into whatever runs next), the step 2.04-2.10 ms.  Kept: the round-2 order
+  // EXPERIMENT (round 4): LIST_FWD_FORK = 8 digits, the stream (0 = caller's, 1..3 = side streams) of
+  // [level 0 .. level 5, I, T]: the gathers of a chunk on several queues (they only run side by side that way)
+  static const char* fork_map = getenv("LIST_FWD_FORK");
+  if (fork_map && strlen(fork_map) >= LIST_N_VOX_LEVELS + 2) {
+    static hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+    for (int i = 0; i < 3; ++i)
+      if (!aux[i] && (e = hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking)) != hipSuccess) return e;
+    hipEvent_t evf;
+    if ((e = hipEventCreateWithFlags(&evf, hipEventDisableTiming)) != hipSuccess) return e;
+    (void)hipEventRecord(evf, s);
+    bool used[4] = {true, false, false, false};
+    hipStream_t saved = s;
+    auto stream_of = [&](int l) { const int k = fork_map[l] - '0'; return (k >= 1 && k <= 3) ? k : 0; };
+    for (int l = 0; l < LIST_N_VOX_LEVELS + 2; ++l) {
+      const int k = stream_of(l);
+      if (k && !used[k]) { (void)hipStreamWaitEvent(aux[k - 1], evf, 0); used[k] = true; }
+    }
+    (void)hipEventDestroy(evf);
+    // launch order: LIST_GATHER_SEQ; every stream's first launch in order, the rest behind it without barriers
+    bool first[4] = {true, true, true, true};
+    bool fdone[LIST_N_VOX_LEVELS + 2] = {false};
+    for (const char* c = LIST_STR(LIST_GATHER_SEQ); ; ++c) {
+      const bool rest = *c == 0;
+      for (int l = 0; l < LIST_N_VOX_LEVELS + 2; ++l) {
+        const bool named = l < LIST_N_VOX_LEVELS ? *c == '0' + l : *c == (l == LIST_N_VOX_LEVELS ? 'I' : 'T');
+        if (fdone[l] || !(rest || named)) continue;
+        fdone[l] = true;
+        if (l < LIST_N_VOX_LEVELS && a.vox[l].C == 1) continue;
+        const int k = stream_of(l);
+        order = first[k] ? 0 : side;
+        first[k] = false;
+        s = k ? aux[k - 1] : saved;
+        if (l < LIST_N_VOX_LEVELS) e = vox_level(l);
+        else e = l == LIST_N_VOX_LEVELS ? img() : tail();
+        s = saved;
+        if (e != hipSuccess) return e;
+      }
+      if (rest) break;
+    }
+    for (int k = 1; k <= 3; ++k) {
+      if (!used[k]) continue;
+      hipEvent_t evj;
+      if ((e = hipEventCreateWithFlags(&evj, hipEventDisableTiming)) != hipSuccess) return e;
+      (void)hipEventRecord(evj, aux[k - 1]);
+      (void)hipStreamWaitEvent(saved, evj, 0);
+      (void)hipEventDestroy(evj);
+    }
+    return hipSuccess;
+  }
   bool done[LIST_N_VOX_LEVELS + 2] = {false};
   for (const char* c = LIST_STR(LIST_GATHER_SEQ); ; ++c) {
     const bool rest = *c == 0;
@@ -865,6 +924,18 @@ static hipError_t launch_gather_fmt(const GatherParams& g, const FeatLayout& L, 
     if (rest) break;
   }
   return hipSuccess;
+}
+
+// bit l set: voxel level l goes to the matrix-core gather (the condition launch_vox_level_t dispatches on)
+int gather_box_levels(const GatherParams& g, const FeatLayout& L, const ListQueryArgs& a) {
+  int mask = 0;
+  for (int l = 0; l < LIST_N_VOX_LEVELS; ++l) {
+    const ListVoxLevel& lv = a.vox[l];
+    const int big = lv.W > lv.H ? (lv.W > lv.D ? lv.W : lv.D) : (lv.H > lv.D ? lv.H : lv.D);
+    const bool near = kDisp * 0.5f * (float)(big - 1) < 0.99f && lv.C >= 16;
+    if (near && gather_box_eligible(g, lv, L.vox_off[l])) mask |= 1 << l;
+  }
+  return mask;
 }
 
 hipError_t launch_gather(const GatherParams& g, const FeatLayout& L, const ListQueryArgs& a,

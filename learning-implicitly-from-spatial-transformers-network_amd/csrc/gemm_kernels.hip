@@ -716,7 +716,12 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_pp(GemmParams p) {
       const int row0 = is_a ? a_quarter_row(q, quarter == 3) : w_quarter_row(q, quarter == 2);
       const int row = row0 + lane / 8;
       const int chunk = (lane % 8) ^ P::swz(row);
+#ifdef LIST_PP_A_RESIDENT     // ablation (wrong results): every tile stages the A rows of the first M-tile -- no HBM stream for A,
+      // the LDS-DMA volume of a 128 x 512 tile that streams W twice and produces its A on chip
+      const char* g = (is_a ? p.a_hi + (int64_t)min(row, a_last) * lda : p.w_hi + (int64_t)(n0 + row) * ldw) + kbyte + chunk * 16;
+#else
       const char* g = (is_a ? p.a_hi + (int64_t)min(m0 + row, a_last) * lda : p.w_hi + (int64_t)(n0 + row) * ldw) + kbyte + chunk * 16;
+#endif
 #ifndef LIST_PP_A_DEFAULT_POLICY
       if (EPI == EPI_RELU_SPLIT && is_a) glds16_nt(g, sbase + row0 * P::kRowBytes);
       else

@@ -117,8 +117,8 @@ GatherParams make_gather(const ListQueryArgs* a, const FeatLayout& L, const Work
 
 // rows the given workspace can hold (multiple of kRowTile, capped at the request), or 0
 int64_t chunk_rows_for(size_t bytes, int64_t P, int Kp, int H1, int H2) {
-  int64_t want = (P + kRowTile - 1) / kRowTile * kRowTile;
-  if (want > kMaxChunkRows) want = kMaxChunkRows;
+  // (clamp first: P comes from the caller, and P + 255 must not overflow -- found by the UBSan host build)
+  int64_t want = P >= kMaxChunkRows ? kMaxChunkRows : (P + kRowTile - 1) / kRowTile * kRowTile;
   if (workspace_layout(want, Kp, H1, H2).total <= bytes) return want;
   if (bytes < workspace_fixed_bytes()) return 0;
   int64_t fit = (int64_t)((bytes - workspace_fixed_bytes()) / workspace_row_bytes(Kp, H1, H2) + kRowTile)
@@ -126,6 +126,17 @@ int64_t chunk_rows_for(size_t bytes, int64_t P, int Kp, int H1, int H2) {
   if (fit > want) fit = want;
   while (fit >= kRowTile && workspace_layout(fit, Kp, H1, H2).total > bytes) fit -= kRowTile;
   return fit >= kRowTile ? fit : 0;
+}
+
+// inference forwards in fp16: fc_1, fc_2 and fc_out as ONE launch (gemm_kernels.hip, k_mlp_tail_f16).  The one
+// predicate behind the dispatch in list_sdf_query_fwd and behind list_query_plan (what a caller's accounting reads).
+bool takes_fused_tail(const ListQueryArgs* a) {
+#ifdef LIST_NO_FUSED_TAIL
+  (void)a;
+  return false;
+#else
+  return a->no_activations && a->precision == LIST_PREC_FP16 && a->H2 == 256 && a->H3 == 256 && a->H1 % 64 == 0;
+#endif
 }
 
 }  // namespace
@@ -278,8 +289,7 @@ size_t list_query_workspace_bytes(int64_t n_points, int32_t F, int32_t H1, int32
   (void)H3;
   if (n_points <= 0 || F <= 0 || H1 <= 0 || H2 <= 0) return 0;
   const int Kp = (F + kKTile - 1) / kKTile * kKTile;
-  int64_t rows = (n_points + kRowTile - 1) / kRowTile * kRowTile;
-  if (rows > kMaxChunkRows) rows = kMaxChunkRows;
+  const int64_t rows = n_points >= kMaxChunkRows ? kMaxChunkRows : (n_points + kRowTile - 1) / kRowTile * kRowTile;
   return workspace_layout(rows, Kp, H1, H2).total;
 }
 
@@ -463,8 +473,7 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
     gp.out_hi = (unsigned short*)(wsb + ws.h2_hi);
     gp.out_lo = terms == 3 ? (unsigned short*)(wsb + ws.h2_lo) : nullptr;
     gp.ldo = a->H2;
-#ifndef LIST_NO_FUSED_TAIL
-    if (a->no_activations && g.fmt == FMT_FP16 && a->H2 == 256 && a->H3 == 256 && a->H1 % 64 == 0) {
+    if (takes_fused_tail(a)) {
       // inference: fc_1, fc_2 and fc_out in one kernel, H2 stays in registers (gemm_kernels.hip, k_mlp_tail_f16)
       mark(LIST_STAGE_FC1);
       e = launch_mlp_tail(gp, wp + pk.w2_hi, (const float*)(wp + pk.b2), (const float*)(wp + pk.w3),
@@ -473,7 +482,6 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
       mark(LIST_STAGE_FC2);
       continue;
     }
-#endif
     e = launch_gemm(gp, terms, EPI_RELU_SPLIT, s);
     if (e != hipSuccess) return hip_fail(e, "fc_1 launch");
     mark(LIST_STAGE_FC1);
@@ -482,15 +490,42 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
     gp.w_hi = wp + pk.w2_hi; gp.w_lo = wp + pk.w2_lo;
     gp.bias = (const float*)(wp + pk.b2);
     gp.N = a->H3; gp.K = a->H2;
-    // H3 is kept with H1 / H2 for list_sdf_query_bwd (its head needs relu(fc_2): mask, dZ3, d fc_out.weight)
-    gp.out_hi = (unsigned short*)(wsb + ws.h3_hi);
-    gp.out_lo = terms == 3 ? (unsigned short*)(wsb + ws.h3_lo) : nullptr;
+    // H3 is kept with H1 / H2 for list_sdf_query_bwd (its head needs relu(fc_2): mask, dZ3, d fc_out.weight) -- by
+    // forwards a backward can follow only: an inference forward that misses the fused tail above (bf16 formats, the
+    // 256^3 grid of config 4 among them) would write 1 KB per point that nobody reads
+    gp.out_hi = a->no_activations ? nullptr : (unsigned short*)(wsb + ws.h3_hi);
+    gp.out_lo = (terms == 3 && !a->no_activations) ? (unsigned short*)(wsb + ws.h3_lo) : nullptr;
     gp.ldo = a->H3;
     gp.w3 = (const float*)(wp + pk.w3); gp.b3 = (const float*)(wp + pk.b3);
     gp.sdf = a->sdf + p0; gp.n_valid = n_valid; gp.order = g.order;
     e = launch_gemm(gp, terms, EPI_RELU_DOT, s);
     if (e != hipSuccess) return hip_fail(e, "fc_2/fc_out launch");
     mark(LIST_STAGE_FC2);
+  }
+  return LIST_OK;
+}
+
+int list_query_plan(const ListQueryArgs* a, ListQueryPlan* plan) {
+  if (!plan) return fail(LIST_ERR_ARG, "plan is NULL");
+  memset(plan, 0, sizeof(*plan));
+  FeatLayout L;
+  if (a && a->B >= 0 && a->N >= 0 && (int64_t)a->B * a->N == 0) return LIST_OK;   // empty query: no launch at all
+  int rc = check_query_common(a, &L);
+  if (rc != LIST_OK) return rc;
+  if (a->H1 <= 0 || a->H2 <= 0) return fail(LIST_ERR_UNSUPPORTED, "hidden sizes %d/%d/%d", a->H1, a->H2, a->H3);
+  const int64_t P = (int64_t)a->B * a->N;
+  const int64_t rows = chunk_rows_for(a->workspace_bytes, P, L.Kp, a->H1, a->H2);
+  if (rows < kRowTile) return fail(LIST_ERR_WORKSPACE, "workspace of %zu bytes cannot hold one %d-row tile",
+                                   a->workspace_bytes, kRowTile);
+  plan->rows_per_chunk = rows;
+  plan->chunks = (int32_t)((P + rows - 1) / rows);
+  plan->fused_tail = takes_fused_tail(a) ? 1 : 0;
+  plan->fc0_k = a->percep_proj ? L.Kp - a->img_C : L.Kp;
+  {
+    const Workspace ws = workspace_layout(rows, L.Kp, a->H1, a->H2);
+    const int n_valid = (int)(P < rows ? P : rows);
+    const GatherParams g = make_gather(a, L, ws, 0, n_valid, (n_valid + kRowTile - 1) / kRowTile * kRowTile);
+    plan->box_levels = gather_box_levels(g, L, *a);
   }
   return LIST_OK;
 }

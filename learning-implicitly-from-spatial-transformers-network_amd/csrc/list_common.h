@@ -290,7 +290,7 @@ constexpr int kWgradMaxSplits = 128;
 
 struct BwdWorkspace {
   size_t scale;                              // float[4]: s, 1/s, sum(dsdf), -
-  size_t h3_hi, h3_lo;                       // fc_2 activations, re-evaluated
+  size_t h3_hi, h3_lo;                       // fc_2 activations, re-evaluated (-DLIST_BWD_REEVAL_FC2 builds only)
   size_t dz3_hi, dz3_lo, dz2_hi, dz2_lo, dz1_hi, dz1_lo;
   size_t dx;                                 // [rows][Kp] fp16 (FP16) or fp32
   size_t slab;                               // wgrad partials, fp32
@@ -317,7 +317,11 @@ inline BwdWorkspace bwd_workspace_layout(int64_t rows, int Kp, int H1, int H2, i
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
   w.scale = take(16);
+#ifdef LIST_BWD_REEVAL_FC2      // (A/B builds only: the backward reads H3 where the forward left it, list_capi.hip)
   w.h3_hi = take((size_t)rows * H3 * 2); w.h3_lo = take((size_t)rows * H3 * 2);
+#else
+  w.h3_hi = w.h3_lo = 0;
+#endif
   w.dz3_hi = take((size_t)rows * H3 * 2); w.dz3_lo = take((size_t)rows * H3 * 2);
   w.dz2_hi = take((size_t)rows * H2 * 2); w.dz2_lo = take((size_t)rows * H2 * 2);
   w.dz1_hi = take((size_t)rows * H1 * 2); w.dz1_lo = take((size_t)rows * H1 * 2);
@@ -449,6 +453,7 @@ hipError_t launch_features_out(const GatherParams& g, const FeatLayout& L, float
 // coarse levels on the matrix cores (gather_box_kernels.hip); eligible: near level, C = 128, fp16 maps and fp16 X
 bool gather_box_eligible(const GatherParams& g, const ListVoxLevel& lv, int col_off);
 hipError_t launch_gather_vox_box(const GatherParams& g, const ListVoxLevel& lv, int col_off, hipStream_t s, int order);
+int gather_box_levels(const GatherParams& g, const FeatLayout& L, const ListQueryArgs& a);     // bitmask of such levels
 // exact (reference skip semantics) redo of the voxel and 2-D gathers for the 256-row tiles flagged in tile_flags
 hipError_t launch_gather_fixup(const GatherParams& g, const FeatLayout& L, const ListQueryArgs& a,
                                const int* tile_flags, hipStream_t s);

@@ -118,6 +118,11 @@ class ListPoolGradArgs(C.Structure):
                 ("grad_trans_mat", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
+class ListQueryPlan(C.Structure):
+    _fields_ = [("rows_per_chunk", C.c_int64), ("chunks", C.c_int32), ("fused_tail", C.c_int32),
+                ("fc0_k", C.c_int32), ("box_levels", C.c_int32), ("reserved_", C.c_int32 * 2)]
+
+
 EXPORTS = {
     "list_img_map_bytes": (C.c_size_t, [C.POINTER(ListMap2D), C.c_int32, C.c_int32, C.c_int32]),
     "list_prep_img_maps": (C.c_int, [C.POINTER(ListMap2D), C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
@@ -137,6 +142,7 @@ EXPORTS = {
                                                 C.c_int32]),
     "list_query_chunk_rows": (C.c_int64, [C.c_size_t, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "list_sdf_query_fwd": (C.c_int, [C.POINTER(ListQueryArgs), C.c_void_p]),
+    "list_query_plan": (C.c_int, [C.POINTER(ListQueryArgs), C.POINTER(ListQueryPlan)]),
     "list_percep_pool_fwd": (C.c_int, [C.POINTER(ListPoolArgs), C.c_void_p]),
     "list_gather_features_fwd": (C.c_int, [C.POINTER(ListQueryArgs), C.c_void_p, C.c_void_p]),
     "list_gemm_nt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -163,7 +169,7 @@ _lib = None
 _lock = threading.Lock()
 
 
-ABI_VERSION = 6          # LIST_ABI_VERSION of the include/list_hip.h these ctypes structs mirror (checked in load())
+ABI_VERSION = 7          # LIST_ABI_VERSION of the include/list_hip.h these ctypes structs mirror (checked in load())
 
 
 def load():
@@ -481,8 +487,11 @@ class QueryContext:
 
 def sdf_query(query, trans_mat, img, vox, packed, perm=(2, 1, 0), scale=2.0, precision="bf16x3",
               percep_feat=None, out=None, stage_events=None, sort_points=True, clamp_hi=136.0,
-              save_for_backward=False, percep_proj=None):
+              save_for_backward=False, percep_proj=None, plan=None):
     """The fused hot path, network/models.py:91-97 -> sdf [B,N] (float32).
+
+    plan: optional dict, filled with what the library dispatches for this call (list_query_plan: chunks,
+    rows_per_chunk, fused_tail, fc0_k) -- per-kernel accounting reads it instead of guessing.
 
     stage_events: optional ctypes array (c_void_p * (n * N_STAGES)) of hipEvent_t handles, one set of N_STAGES
     per row chunk (query_chunks() says how many chunks a query of B*N points takes).
@@ -512,6 +521,11 @@ def sdf_query(query, trans_mat, img, vox, packed, perm=(2, 1, 0), scale=2.0, pre
     if not sdf.is_contiguous() or sdf.dtype != torch.float32 or tuple(sdf.shape) != (B, N):
         raise RuntimeError("out must be a contiguous float32 [B,N] tensor")
     a.sdf = sdf.data_ptr()
+    if plan is not None:
+        pl = ListQueryPlan()
+        _check(lib.list_query_plan(C.byref(a), C.byref(pl)), "list_query_plan")
+        plan.update(chunks=pl.chunks, rows_per_chunk=pl.rows_per_chunk, fused_tail=pl.fused_tail, fc0_k=pl.fc0_k,
+                    box_levels=pl.box_levels)
     with torch.cuda.device(query.device):
         _check(lib.list_sdf_query_fwd(C.byref(a), _stream()), "list_sdf_query_fwd")
     if save_for_backward:

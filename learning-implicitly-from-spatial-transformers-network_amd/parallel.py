@@ -20,6 +20,16 @@ def world_info(group=None):
     return 0, 1
 
 
+def _local_only(world, group=None):
+    """True when an exchange is a no-op: one process.  LIST_FORCE_COLLECTIVES=1 sends a one-rank process group down
+    the collective branches all the same -- the pre-flight of the RCCL code paths on a one-GPU box
+    (tests/test_rccl_preflight_gpu.py): the calls, dtypes, layouts and the async work handle are those of N ranks."""
+    import os
+    if world > 1:
+        return False
+    return not (os.environ.get("LIST_FORCE_COLLECTIVES", "0") == "1" and dist.is_available() and dist.is_initialized())
+
+
 def shard_range(total, rank, world):
     """Contiguous, balanced [begin, end) of `total` items for `rank` (first `total % world` ranks
     get one extra item)."""
@@ -36,7 +46,7 @@ def gather_sdf_shards(sdf_local, out=None, group=None, async_op=False):
     current stream after it (needed before `out` is read or `sdf_local` is overwritten).  Other backends and a
     single process complete in place and return (out, None)."""
     rank, world = world_info(group)
-    if world == 1:
+    if _local_only(world, group):
         if out is None:
             out = sdf_local
         else:
@@ -64,7 +74,7 @@ def gather_batch_ragged(sdf_local, batch_global, group=None):
     buffer of ceil(batch_global / world) images of which it fills its own, the result is trimmed to
     [batch_global, N] in rank order.  The same padded exchange bench.py --scaling strong keeps in its timed step."""
     rank, world = world_info(group)
-    if world == 1:
+    if _local_only(world, group):
         return sdf_local
     b_pad = -(-batch_global // world)
     b, e = shard_range(batch_global, rank, world)
@@ -84,7 +94,7 @@ def gather_ragged_points(values_local, total, group=None):
     """All-gather of ragged 1-D shards produced with shard_range (query-axis partition of one
     image's grid): pads to the largest shard, gathers, and trims -> [total]."""
     rank, world = world_info(group)
-    if world == 1:
+    if _local_only(world, group):
         return values_local
     longest = (total + world - 1) // world
     pad = torch.zeros((longest,), dtype=values_local.dtype, device=values_local.device)
@@ -116,7 +126,7 @@ def full_batch_value(local, full):
 def all_reduce_mean(value, group=None):
     """Mean over the ranks of a (detached) scalar / small tensor."""
     rank, world = world_info(group)
-    if world == 1:
+    if _local_only(world, group):
         return value.detach()
     v = value.detach().clone()
     if v.is_cuda and dist.get_backend(group) != "nccl":
@@ -133,7 +143,7 @@ def broadcast_from_rank0(tensors, group=None):
     maps, so that the sharded SDF grid is the unsharded one bit for bit even though MIOpen's convolutions are not
     run-to-run deterministic."""
     rank, world = world_info(group)
-    if world == 1:
+    if _local_only(world, group):
         return tensors
     for t in tensors:
         if t.is_cuda and dist.get_backend(group) != "nccl":

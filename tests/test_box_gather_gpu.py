@@ -45,3 +45,46 @@ def test_mfma_gather_of_the_coarse_levels_against_the_scalar_kernel(tmp_path):
     # per-sample canonical arithmetic: the point order (Morton / none) does not change a bit, in either kernel
     np.testing.assert_array_equal(box["sdf_sorted"], box["sdf_unsorted"])
     np.testing.assert_array_equal(ref["sdf_sorted"], ref["sdf_unsorted"])
+
+
+def test_mfma_gather_of_the_coarse_levels_against_the_oracle():
+    """The matrix-core gather against the ORACLE (oracle.list_oracle.vox_features = network/modules.py:256-273 in numpy),
+    not against another HIP kernel: the 16^3 and 8^3 x 128-channel levels at the metric's map sizes, points on faces and
+    corners included.  The oracle samples the fp16-ROUNDED maps (what the prepared levels hold) in fp32; X then holds
+    that value rounded to fp16: one fp16 ulp (2^-10 relative) + 5e-7 where the taps cancel."""
+    import torch
+    import __graft_entry__ as ge
+    ge.build()
+    from list_amd import hip
+    from list_amd import synthetic as synth
+    from oracle import list_oracle as O            # the checker
+    assert os.environ.get("LIST_GATHER_BOX", "1") != "0"
+    seed, B, N = 808, 2, 6000
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    q = synth.make_query(seed, B, N)
+    q[0, :8] = np.array([[s0, s1, s2] for s0 in (-0.5, 0.5) for s1 in (-0.5, 0.5) for s2 in (-0.5, 0.5)], np.float32)
+    q[1, :3] = np.array([[0.5, 0.1, -0.2], [0.0, -0.5, 0.3], [0.49, 0.49, 0.0]], np.float32)
+    vox_maps = synth.make_vox_maps(seed, B, 128)
+    img = hip.prep_img_maps([dev(m) for m in synth.make_img_maps(seed, B, 224)], dtype="f16")
+    vox = hip.prep_vox_maps([dev(m) for m in vox_maps], dtype="f16")
+    packed = hip.prep_mlp_weights({k: dev(v) for k, v in synth.make_mlp_weights(seed).items()}, vox.channels,
+                                  img.channels, "fp16")
+    tm = dev(synth.make_trans_mat(seed, B))
+    # the library's own word on what it dispatches for these arguments: levels 4 and 5 on the matrix cores
+    plan = {}
+    hip.sdf_query(dev(q), tm, img, vox, packed, precision="fp16", plan=plan)
+    assert plan["box_levels"] == (1 << 4) | (1 << 5), plan
+    feats = hip.gather_features(dev(q), tm, img, vox, packed).cpu().numpy()
+    lo = 7 * (1 + 16 + 32 + 64)
+    got = feats[:, lo:lo + 7 * 256]
+    coarse16 = [m.astype(np.float16).astype(np.float32) for m in vox_maps[4:6]]
+    assert coarse16[0].shape[1:] == (128, 16, 16, 16) and coarse16[1].shape[1:] == (128, 8, 8, 8)
+    want = O.vox_features(O.permute_scale_query(q), coarse16)          # [B, 256 * 7, N], k = c * 7 + j
+    assert want.shape == got.shape and np.abs(want).max() > 1.0
+    tol = np.abs(want) * 2.0 ** -10 + 5e-7
+    worst = float((np.abs(got - want) / tol).max())
+    print(f"box gather vs oracle: worst {worst:.3f} of (1 fp16 ulp + 5e-7)")
+    assert worst <= 1.0, worst
+    # the face / corner points sit on border taps (clipped coordinates, dropped taps): checked separately
+    edge = np.abs(got[0, :, :8] - want[0, :, :8]) / tol[0, :, :8]
+    assert float(edge.max()) <= 1.0
