@@ -441,6 +441,15 @@ def run_train_step(precision, steps, warmup, inp, hip, ev):
             "outputs": "d fc_0..fc_out (reference layout), d 5 image maps, d 6 voxel maps, d trans_mat"}, grads
 
 
+def _on_clamp(query, trans_mat, clamp_hi=136.0):
+    """Fraction of the query points whose projection (network/modules.py:37-43) sits on the clamp."""
+    q = query[:, :, [2, 1, 0]] * 2
+    h = torch.cat([q, torch.ones_like(q[..., :1])], -1) @ trans_mat.reshape(-1, 4, 3)
+    uv = h[..., :2] / (h[..., 2:3] + 1e-8)
+    on = ((uv <= 0) | (uv >= clamp_hi)).any(-1)
+    return on.float().mean()
+
+
 def run_whole_model(workload, precision, device, steps=5, warmup=2):
     """the whole LIST.forward (ResNet encoders, coarse point decoder, on-device create_occ, 3-D
     encoder, spatial transformer AND the HIP query path) on the same B x N, so the weight of the path
@@ -474,7 +483,45 @@ def run_whole_model(workload, precision, device, steps=5, warmup=2):
                     times["encode"] += t1 - t0
                     times["query"] += t2 - t1
         total = (times["encode"] + times["query"]) / steps
-        return net, sdf, {"ms_per_forward": total * 1e3, "value": B * N / total,
+        # ---- where the query's wall time goes (2.40 ms here against 1.80 ms for the same B x N in the
+        # bench's own channels-last step).  (i) the call timed above starts on an IDLE device behind a synchronize: its
+        # first launch waits for the Python dispatch; (ii) the same call with the device kept busy (no synchronize
+        # between encode and query: what train.py / test.py do), as GPU time between two events; (iii) its stages
+        # (hip.STAGE_EVENTS_HOOK); (iv) the same module call on the SYNTHETIC camera of SURVEY 8d instead of the
+        # untrained spatial transformer's output, whose projections pile onto the clamp.
+        from list_amd import hip as _hip
+        from list_amd import synthetic as _synth
+        evs = HipEvents()
+        diag = {}
+        with torch.no_grad():
+            feat_l2, vox_feat, tm, _, _ = net.encode(img)
+            tm_syn = torch.from_numpy(_synth.make_trans_mat(333, B)).to(device)
+            for name, T in (("model_trans_mat", tm), ("synthetic_camera", tm_syn)):
+                gpu, stages = [], np.zeros(_hip.N_STAGES - 1)
+                for it in range(6):
+                    arr = (ctypes.c_void_p * _hip.N_STAGES)(*[evs.create() for _ in range(_hip.N_STAGES)]) if it >= 3 else None
+                    _hip.STAGE_EVENTS_HOOK = arr
+                    f2 = [m.clone(memory_format=torch.preserve_format) for m in feat_l2]     # new maps: the caches miss, as in a forward
+                    e0, e1 = evs.create(), evs.create()
+                    evs.record(e0)
+                    net.query_sdf(query, f2, vox_feat, T)
+                    evs.record(e1)
+                    _hip.STAGE_EVENTS_HOOK = None
+                    torch.cuda.synchronize()
+                    if it >= 3:
+                        gpu.append(evs.elapsed_ms(e0, e1))
+                        # (stage events between the gathers put their queue barriers back: +2 % on the group)
+                        stages += np.array([evs.elapsed_ms(ctypes.c_void_p(arr[i]), ctypes.c_void_p(arr[i + 1]))
+                                            for i in range(_hip.N_STAGES - 1)]) / 3
+                st = dict(zip(_hip.STAGE_NAMES, [round(float(x), 4) for x in stages]))
+                diag[name] = {"gpu_ms_first_to_last_event": round(float(np.mean(gpu)), 4),
+                              "prep_and_dispatch_before_sort_ms": round(float(np.mean(gpu)) - float(stages.sum()), 4),
+                              "stage_ms": st, "frac_points_on_clamp": float(_on_clamp(query, T))}
+        diag["wall_from_idle_minus_gpu_ms"] = round(times["query"] / steps * 1e3 - diag["model_trans_mat"]["gpu_ms_first_to_last_event"], 4)
+        diag["note"] = ("query_sdf_ms is wall clock of one call started on an idle device (synchronize on both sides): "
+                        "host dispatch before the first launch is exposed; gpu_ms_first_to_last_event is the same call "
+                        "between two events with the host running ahead")
+        return net, sdf, {"ms_per_forward": total * 1e3, "value": B * N / total, "query_breakdown": diag,
                           # SURVEY 8d's second run: the query path fed by the model's own (untrained) spatial transformer
                           # and encoders instead of the synthetic camera and maps
                           "query_path_points_per_s": B * N / (times["query"] / steps),

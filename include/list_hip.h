@@ -251,7 +251,9 @@ typedef struct ListQueryPlan {
                             /*    args->percep_proj is given)                                                      */
   int32_t box_levels;       /* bit l: voxel level l is gathered on the matrix cores (k_gather_vox_box: a level whose  */
                             /*    stencil stays inside one cell, 128 channels, fp16 maps and fp16 operands)           */
-  int32_t reserved_[2];
+  int32_t fused_fc0;        /* 1: fc_0 produces the perceptual block of its A operand on chip (k_fc0_fused) and no 2-D   */
+                            /*    gather kernel is launched; 0: k_gather_img writes the block into X                     */
+  int32_t reserved_[1];
 } ListQueryPlan;
 int list_query_plan(const ListQueryArgs* args, ListQueryPlan* plan);
 

@@ -1,0 +1,225 @@
+// fc_0 with the perceptual block of its A operand produced ON CHIP (round 4; north_star: "LDS staging of the sampled
+// feature tiles").  network/modules.py:46-53 (bilinear sample of the 137^2 map) + :275-276 (concat, fc_0 + ReLU) for a
+// tile of 128 query points and ALL 512 output columns per workgroup:
+//
+//   * K-tiles 0 .. img_C/64 - 1 (the perceptual block leads the gather order, list_common.h): every thread loads the 4
+//     taps of its two (row, 8-channel) items straight from the prepared map into registers -- two K-tiles ahead of the
+//     MFMAs that consume them --, interpolates in fp32 with the arithmetic of k_gather_img (gather_math.h: same products,
+//     same order, same fp16 rounding) and writes the fp16 result into the A stage in LDS.  Those 1024 columns of X are
+//     never written to or read from HBM (0.33 GB + 0.36 GB per 160 k points), and k_gather_img is not launched.
+//   * the other K-tiles (voxel levels, xyz) come from X by LDS-DMA as in k_gemm_nt_pp.
+//   * W streams from L2 by LDS-DMA, one 64-KB K-tile of all 512 rows per step (a row tile sees W once; with the
+//     256 x 256 tile of k_gemm_nt_pp it is read by two workgroups per row tile, each with half of it).
+//
+// Tile: 8 waves as 2 (M) x 4 (N), wave = 64 rows x 128 columns = 4 x 8 tiles of v_mfma_f32_16x16x32_f16 (128
+// accumulator registers).  LDS 160 KB: W 2 x 64 KB, A 2 x 16 KB; rows of 128 B, 16-B chunks XOR-swizzled with (row>>1)&7
+// (on the LDS-DMA source address / the ds_write address, and on the ds_read_b128 address) as in gemm_kernels.hip.
+// Same MFMA, same operand roles and the same k order per output element as k_gemm_nt_pp: bit-identical to the unfused
+// path (tests/test_fused_fc0_gpu.py).  The NaN probe / exact redo of flagged 256-row tiles is unchanged: the fix-up
+// kernel rewrites the whole X row of such tiles (perceptual block included) and the gated k_gemm_nt_pp re-runs on it.
+#include "list_common.h"
+#include "mfma_common.h"
+#include "point_math.h"
+#include "gather_math.h"
+
+namespace list {
+
+constexpr int kFusedLds = 163840;
+constexpr int kFW = 65536, kFA = 16384;            // bytes per W / A stage
+constexpr int kFAOff = 2 * kFW;                     // A stages behind the two W stages
+
+
+__device__ __forceinline__ int fswz(int row) { return (row >> 1) & 7; }
+
+// per-thread record of one row's projection (project(), point_math.h), packed: what the four tap loads need
+struct RowProj { int64_t base; int dx, dy; float w00, w01, w10, w11; int valid; };
+
+__global__ __launch_bounds__(512, 2) void k_fc0_fused(FusedFc0Params fp) {
+  using M = MapT<1>;
+  __shared__ __attribute__((aligned(16))) char smem[kFusedLds];
+  const GemmParams& p = fp.gp;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int ntiles = p.M / 128;
+  const int m0 = xcd_contiguous_block(blockIdx.x, ntiles) * 128;
+  const int nk = p.K / 64;
+  const int np = fp.n_produced;
+  const int64_t lda = (int64_t)p.K * 2, ldw = (int64_t)p.K * 2;
+
+  // ---- the two items of this thread in a produced K-tile: rows r0, r0 + 64, chunk c (8 channels = 16 B)
+  const int pc = tid & 7, pr = tid >> 3;
+  RowProj rp[2];
+  if (np > 0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const Pt pt = load_point(fp.g, m0 + pr + 64 * h);
+      const Proj q = project(fp.trans_mat + pt.b * 12, pt.x, pt.y, pt.z, fp.ms, fp.Ct, fp.clamp_hi);
+      rp[h].base = (int64_t)pt.b * fp.ms * fp.ms * fp.Ct + q.o00 + pc * 8;
+      rp[h].dx = q.o01 - q.o00; rp[h].dy = q.o10 - q.o00;        // (o11 = o00 + dx + dy: x1, y1 are clamped separately)
+      rp[h].w00 = q.w00; rp[h].w01 = q.w01; rp[h].w10 = q.w10; rp[h].w11 = q.w11;
+      rp[h].valid = pt.valid ? 1 : 0;
+    }
+  }
+  M::Raw taps[2][4];
+  auto load_taps = [&](int t) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int64_t o = rp[h].base + t * 64;
+      taps[h][0] = M::load(fp.img_map, o);
+      taps[h][1] = M::load(fp.img_map, o + rp[h].dx);
+      taps[h][2] = M::load(fp.img_map, o + rp[h].dy);
+      taps[h][3] = M::load(fp.img_map, o + rp[h].dy + rp[h].dx);
+    }
+  };
+  auto produce = [&](char* astage) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float r[8];
+      tap_mul<M>(taps[h][0], rp[h].w00, r); tap_fma<M>(taps[h][1], rp[h].w01, r);
+      tap_fma<M>(taps[h][2], rp[h].w10, r); tap_fma<M>(taps[h][3], rp[h].w11, r);
+      const bool v = rp[h].valid != 0;
+      const uint2 lo = half4_inrange(v ? make_float4(r[0], r[1], r[2], r[3]) : make_float4(0.f, 0.f, 0.f, 0.f));
+      const uint2 hi = half4_inrange(v ? make_float4(r[4], r[5], r[6], r[7]) : make_float4(0.f, 0.f, 0.f, 0.f));
+      const int row = pr + 64 * h;
+      *(uint4*)(astage + row * 128 + ((pc ^ fswz(row)) << 4)) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+  };
+
+  // ---- LDS-DMA staging: W K-tile (64 pieces of 8 rows, 8 per wave), A K-tile from X (16 pieces, 2 per wave)
+  const int a_last = p.M - 1;
+  auto stage_w = [&](int t, char* wstage) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int piece = 8 * wave + r;
+      const int row = piece * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ fswz(row);
+      glds16(p.w_hi + (int64_t)row * ldw + t * 128 + chunk * 16, wstage + piece * 1024);
+    }
+  };
+  auto stage_a = [&](int t, char* astage) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int piece = 2 * wave + r;
+      const int row = piece * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ fswz(row);
+      glds16_nt(p.a_hi + (int64_t)min(m0 + row, a_last) * lda + t * 128 + chunk * 16, astage + piece * 1024);
+    }
+  };
+
+  f32x4v acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+  const int frow = lane & 15, fo = lane >> 4;
+  const int fsw = fswz(frow);                                   // block row offsets are multiples of 16
+  const int a_row_off = (wm * 64 + frow) * 128;
+  const int w_row_off = (wn * 128 + frow) * 128;
+
+  // ---- prologue: tile 0 (produced or staged), taps of tile 1 in flight
+  if (np > 0) {
+    load_taps(0);
+    wait_vmcnt<0>();
+    produce(smem + kFAOff);
+    stage_w(0, smem);
+    if (np > 1) load_taps(1);
+  } else {
+    stage_w(0, smem);
+    stage_a(0, smem + kFAOff);
+  }
+
+  for (int t = 0; t < nk; ++t) {
+    // W(t) (and A(t) when it is staged) have landed; the taps of tile t + 1 (8 younger loads) may stay in flight.
+    // My ds_writes of a produced A(t) are complete.
+    if (t + 1 < np) wait_vmcnt<8>(); else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int nxt = (t + 1) & 1;
+    const bool more = t + 1 < nk;
+    const bool next_staged = more && (t + 1 >= np);
+    if (more) stage_w(t + 1, smem + nxt * kFW);
+    if (next_staged) stage_a(t + 1, smem + kFAOff + nxt * kFA);
+
+    const char* aw = smem + kFAOff + (t & 1) * kFA;
+    const char* ww = smem + (t & 1) * kFW;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int coff = ((4 * ks + fo) ^ fsw) << 4;
+      bf16x8 a[4], w[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)(aw + a_row_off + i * 16 * 128 + coff);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = *(const bf16x8*)(ww + w_row_off + j * 16 * 128 + coff);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = mfma16<1>(a[i], w[j], acc[i][j]);
+    }
+
+    if (t + 1 < np) {
+      // the taps of tile t + 1 were requested one iteration ago, before this iteration's 8 W pieces.  (Measured and
+      // dropped, round 4: the two waves of a SIMD taking this block on opposite sides of their MFMAs, 0.642 -> 0.669 ms.)
+      wait_vmcnt<8>();
+      produce(smem + kFAOff + nxt * kFA);
+      if (t + 2 < np) load_taps(t + 2);
+    }
+  }
+
+  // ---- epilogue: bias + ReLU + fp16, staged through LDS (32 rows x 64 columns per wave and turn) for 16-B stores
+  {
+    float* tile = (float*)smem + wave * (32 * kStageLd);
+    const int col_in = lane & 15, row_in = 4 * (lane >> 4);
+    const int rr = lane >> 3, c8 = (lane & 7) * 8;
+    const int64_t row_base = m0 + wm * 64;
+    const int col_base = wn * 128;
+    bool bad = false;
+    __syncthreads();                                 // every wave is done with the operand stages
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+      for (int jh = 0; jh < 2; ++jh) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              tile[(ii * 16 + row_in + e) * kStageLd + jj * 16 + col_in] = acc[2 * ih + ii][4 * jh + jj][e];
+        __syncthreads();
+        const int cb = col_base + jh * 64 + c8;
+        const float4 b0 = *(const float4*)(p.bias + cb), b1 = *(const float4*)(p.bias + cb + 4);
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int r = rr + 8 * k;
+          const float4 x = *(const float4*)(tile + r * kStageLd + c8);
+          const float4 y = *(const float4*)(tile + r * kStageLd + c8 + 4);
+          const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { o[e] = relu_nan(v[e] + bb[e]); bad = bad || (o[e] != o[e]); }
+          store8_planes<1>(p.out_hi, nullptr, (row_base + ih * 32 + r) * p.ldo + cb, o);
+        }
+        __syncthreads();
+      }
+    // NaN probe for the exact redo of the 256-row tile's gathers (gemm_kernels.hip, gemm_epilogue16)
+    if (p.nan_tiles && __builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) p.nan_tiles[m0 / 256] = 1;
+  }
+}
+
+bool fused_fc0_eligible(const GemmParams& gp, int img_f16, int img_C) {
+  return gp.fmt == FMT_FP16 && gp.N == 512 && gp.M > 0 && gp.M % 128 == 0 && gp.K % 64 == 0 && img_f16 && img_C > 0 &&
+         img_C % 64 == 0 && img_C <= gp.K && gp.bias && !gp.rowvec && !gp.lda && !gp.ldw && !gp.a_rows && !gp.tile_gate;
+}
+
+hipError_t launch_fc0_fused(const FusedFc0Params& fp, hipStream_t s) {
+  hipLaunchKernelGGL(k_fc0_fused, dim3(fp.gp.M / 128), dim3(512), 0, s, fp);
+  return hipGetLastError();
+}
+
+}  // namespace list

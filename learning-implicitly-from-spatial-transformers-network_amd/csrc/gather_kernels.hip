@@ -10,51 +10,9 @@
 
 #include "list_common.h"
 #include "point_math.h"
+#include "gather_math.h"
 
 namespace list {
-
-// ---- map element formats -------------------------------------------------------------------------------
-// A lane owns V consecutive channels of a channels-last map: 4 floats (fp32 maps) or 8 halfs (fp16
-// maps); either way one 16-B load per tap.  All interpolation arithmetic is fp32.
-template <int F16> struct MapT;
-template <> struct MapT<0> {
-  static constexpr int V = 4;
-  using Raw = float4;
-  static __device__ __forceinline__ Raw load(const void* base, int64_t off) {
-    return *(const float4*)((const float*)base + off);
-  }
-  static __device__ __forceinline__ void unpack(const Raw& r, float (&f)[4]) {
-    f[0] = r.x; f[1] = r.y; f[2] = r.z; f[3] = r.w;
-  }
-};
-template <> struct MapT<1> {
-  static constexpr int V = 8;
-  using Raw = uint4;
-  static __device__ __forceinline__ Raw load(const void* base, int64_t off) {
-    return *(const uint4*)((const unsigned short*)base + off);
-  }
-  static __device__ __forceinline__ void unpack(const Raw& r, float (&f)[8]) {
-    f[0] = h2f((unsigned short)(r.x & 0xffff)); f[1] = h2f((unsigned short)(r.x >> 16));
-    f[2] = h2f((unsigned short)(r.y & 0xffff)); f[3] = h2f((unsigned short)(r.y >> 16));
-    f[4] = h2f((unsigned short)(r.z & 0xffff)); f[5] = h2f((unsigned short)(r.z >> 16));
-    f[6] = h2f((unsigned short)(r.w & 0xffff)); f[7] = h2f((unsigned short)(r.w >> 16));
-  }
-};
-
-template <typename M>
-__device__ __forceinline__ void tap_mul(const typename M::Raw& r, float w, float (&a)[M::V]) {
-  float f[M::V];
-  M::unpack(r, f);
-#pragma unroll
-  for (int c = 0; c < M::V; ++c) a[c] = f[c] * w;
-}
-template <typename M>
-__device__ __forceinline__ void tap_fma(const typename M::Raw& r, float w, float (&a)[M::V]) {
-  float f[M::V];
-  M::unpack(r, f);
-#pragma unroll
-  for (int c = 0; c < M::V; ++c) a[c] = fmaf(f[c], w, a[c]);
-}
 
 // ---- exact border semantics (cold path) -----------------------------------------------------------------
 // The fast reductions multiply a tap the reference SKIPS (index == size under border padding, outside the map
@@ -379,16 +337,54 @@ __global__ __launch_bounds__(256) void k_zero_i32(int4* __restrict__ p, int n4) 
   if (i < n4) p[i] = make_int4(0, 0, 0, 0);
 }
 
+// Counter updates, one atomic per KEY per wave (round 4).  The lanes of a wave that hold the same key are found by a
+// 64-step compare against every lane's key (v_readlane with a constant lane: ~4 instructions per step, no memory
+// traffic) and their first lane adds the group's count in ONE atomic; every lane gets base + its rank in the group.
+// Why: projections that pile onto the clamp (network/modules.py:43 -- an untrained spatial transformer puts 88 % of the
+// points there, bench.py --whole-model) sent tens of thousands of atomics to a handful of pixel counters, which the
+// memory side executes one after the other: the point sort took 0.74 ms instead of 0.054 ms, the whole gap between the
+// module path's 2.40 ms and the bench's 1.80 ms.  Evenly spread keys cost the same as before (one atomic per lane).
+// All 64 lanes must be live (no early exit before this): `active` = false lanes match nobody and add nothing.
+__device__ __forceinline__ int wave_grouped_add(int* __restrict__ bins, int key, bool active, bool want_pos) {
+  const int lane = threadIdx.x & 63;
+  const int k = active ? key : (-1 - lane);             // real keys are >= 0
+  unsigned lo = 0, hi = 0;                              // lanes that hold my key
+#pragma unroll
+  for (int l = 0; l < 64; ++l) {
+    const int kl = __builtin_amdgcn_readlane(k, l);
+    if (l < 32) lo |= (kl == k) ? (1u << l) : 0u;
+    else hi |= (kl == k) ? (1u << (l - 32)) : 0u;
+  }
+  const unsigned below_lo = lane < 32 ? lo & ((1u << lane) - 1u) : lo;
+  const unsigned below_hi = lane < 32 ? 0u : hi & ((1u << (lane - 32)) - 1u);
+  const int rank = __builtin_popcount(below_lo) + __builtin_popcount(below_hi);
+  const int count = __builtin_popcount(lo) + __builtin_popcount(hi);
+  int base = 0;
+  if (active && rank == 0) base = atomicAdd(&bins[key], count);
+  if (!want_pos) return 0;
+  const int first = lo ? __builtin_ctz(lo) : 32 + __builtin_ctz(hi);
+  return __shfl(base, first) + rank;
+}
+
 // Both orders are built by the same three launches: bins = [Morton counters | pixel counters].
 __global__ __launch_bounds__(256) void k_sort_hist(GatherParams g, SortParams sp, int* __restrict__ keys_m,
                                                    int* __restrict__ keys_p, int* __restrict__ bins_m,
                                                    int* __restrict__ bins_p) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= g.n_valid) return;
-  const SortKeys k = sort_keys(g, sp, i);
-  keys_m[i] = k.morton;
-  atomicAdd(&bins_m[k.morton], 1);
-  if (sp.pixel) { keys_p[i] = k.pixel; atomicAdd(&bins_p[k.pixel], 1); }
+  const bool active = i < g.n_valid;
+  SortKeys k;
+  k.morton = 0; k.pixel = 0;
+  if (active) {
+    k = sort_keys(g, sp, i);
+    keys_m[i] = k.morton;
+    if (sp.pixel) keys_p[i] = k.pixel;
+  }
+#ifdef LIST_SORT_PLAIN_ATOMICS      // A/B: one atomic per point
+  if (active) { atomicAdd(&bins_m[k.morton], 1); if (sp.pixel) atomicAdd(&bins_p[k.pixel], 1); }
+#else
+  wave_grouped_add(bins_m, k.morton, active, false);
+  if (sp.pixel) wave_grouped_add(bins_p, k.pixel, active, false);
+#endif
 }
 
 // Exclusive scan of the counters, one workgroup per (order, image slot).  The number of points of
@@ -428,13 +424,23 @@ __global__ __launch_bounds__(256) void k_sort_scatter(int n_valid, const int* __
                                                       int* __restrict__ bins_p, int* __restrict__ order,
                                                       int* __restrict__ row_of, int* __restrict__ order_img) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_valid) return;
+  const bool active = i < n_valid;
+#ifdef LIST_SORT_PLAIN_ATOMICS
+  if (!active) return;
   const int pos = atomicAdd(&bins_m[keys_m[i]], 1);
   order[pos] = i;
   if (order_img) {
     row_of[i] = pos;
     order_img[atomicAdd(&bins_p[keys_p[i]], 1)] = i;
   }
+#else
+  const int pos = wave_grouped_add(bins_m, active ? keys_m[i] : 0, active, true);
+  if (active) order[pos] = i;
+  if (order_img) {                                   // (uniform: a kernel argument)
+    const int pp = wave_grouped_add(bins_p, active ? keys_p[i] : 0, active, true);
+    if (active) { row_of[i] = pos; order_img[pp] = i; }
+  }
+#endif
 }
 
 hipError_t launch_sort_points(const GatherParams& g, const ListQueryArgs& a, const SortBuffers& sb,
@@ -788,7 +794,7 @@ static hipError_t launch_vox_level(const GatherParams& g, const ListVoxLevel& lv
 
 template <int FMT>
 static hipError_t launch_gather_fmt(const GatherParams& g, const FeatLayout& L, const ListQueryArgs& a,
-                                    int* nan_tiles, hipStream_t s) {
+                                    int* nan_tiles, hipStream_t s, bool skip_img) {
   hipError_t e = hipSuccess;
   auto mark = [&](int stage) {
     if (a.stage_events && a.stage_events[stage]) (void)hipEventRecord((hipEvent_t)a.stage_events[stage], s);
@@ -816,6 +822,7 @@ static hipError_t launch_gather_fmt(const GatherParams& g, const FeatLayout& L, 
     }
   };
   auto img = [&]() -> hipError_t {
+    if (skip_img) return hipSuccess;      // the perceptual block is produced inside fc_0 (fused_fc0_kernels.hip)
     if (a.percep_proj) {          // projected perceptual map: H1 channels, fp16 (fp16 operands) or fp32
       if (FMT == FMT_FP16)
         LIST_LAUNCH((k_gather_img<FMT, 1, 1>), dim3(g.rows / kGatherRows), dim3(256), 0, s, order, g, a.percep_proj,
@@ -939,9 +946,9 @@ int gather_box_levels(const GatherParams& g, const FeatLayout& L, const ListQuer
 }
 
 hipError_t launch_gather(const GatherParams& g, const FeatLayout& L, const ListQueryArgs& a,
-                         int* nan_tiles, hipStream_t s) {
-  return g.fmt == FMT_FP16 ? launch_gather_fmt<FMT_FP16>(g, L, a, nan_tiles, s)
-                           : launch_gather_fmt<FMT_BF16_SPLIT>(g, L, a, nan_tiles, s);
+                         int* nan_tiles, hipStream_t s, bool skip_img) {
+  return g.fmt == FMT_FP16 ? launch_gather_fmt<FMT_FP16>(g, L, a, nan_tiles, s, skip_img)
+                           : launch_gather_fmt<FMT_BF16_SPLIT>(g, L, a, nan_tiles, s, skip_img);
 }
 
 // ---- diagnostics: X (gather order, hi+lo) -> out[B][F][N] in the reference order ---------------------

@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "list_common.h"
+#include "mfma_common.h"
 
 namespace list {
 
@@ -53,27 +54,6 @@ template <int TERMS> struct Pipe {
     return kRowBytes == 64 ? ((row >> 2) & 3) : ((row >> 1) & 7);
   }
 };
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-#ifdef LIST_GEMM_NO_VMWAIT   // ablation (wrong results): loads are issued but their landing is never waited for
-  if (N != 0) return;
-#endif
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-__device__ __forceinline__ void glds16(const char* g, char* l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-}
-// the same with the non-temporal cache policy (aux = 2): the A stream of the forward's hidden layers (X into fc_0, H1
-// into fc_1) -- rows that at most two N-tiles of one XCD read, back to back, and nobody afterwards.  Round 3, four
-// interleaved pairs on one device: fc_0 0.497 -> 0.492 ms, step -0.012 ms.  (Weights, and the A operand of the
-// backward's dX -- fifteen N-tiles per row --, keep the default policy.)
-__device__ __forceinline__ void glds16_nt(const char* g, char* l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)l, 16, 0, 2);
-}
 
 // Each wave stages kPiecesPerWave 1-KB pieces of every plane.  Lane i of a piece writes LDS bytes
 // [16 i, 16 i + 16) of the piece = (row i / chunks_per_row, physical chunk i % chunks_per_row); it
@@ -120,7 +100,6 @@ __device__ __forceinline__ unsigned short to_half_plane(float v) { return FP16 ?
 // same again for every per-element input (ReLU mask).  Instead each wave turns its 128 x 64 tile through
 // LDS, 32 rows at a time (the operand stages are dead by then), and every lane gets 8 consecutive columns
 // of a row: one 16-B load per input plane, one 16-B store per output plane, 128-B runs per row.
-constexpr int kStageLd = 68;                       // floats per staged row: 64 + 4 (row r starts 4 banks on)
 
 template <typename F>
 __device__ __forceinline__ void staged_epilogue(const f32x16 (&acc)[4][2], char* smem, int wave, int lane,
@@ -147,24 +126,6 @@ __device__ __forceinline__ void staged_epilogue(const f32x16 (&acc)[4][2], char*
     }
     __syncthreads();
   }
-}
-
-template <int FP16>
-__device__ __forceinline__ void store8_planes(unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
-                                              int64_t off, const float (&v)[8]) {
-  unsigned h[4], l[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    if (FP16) {
-      h[e] = f2h2(v[2 * e], v[2 * e + 1]);
-    } else {
-      const unsigned short h0 = f2bf(v[2 * e]), h1 = f2bf(v[2 * e + 1]);
-      h[e] = (unsigned)h0 | ((unsigned)h1 << 16);
-      l[e] = (unsigned)bf_lo(v[2 * e], h0) | ((unsigned)bf_lo(v[2 * e + 1], h1) << 16);
-    }
-  }
-  *(uint4*)(hi + off) = make_uint4(h[0], h[1], h[2], h[3]);
-  if (!FP16 && lo) *(uint4*)(lo + off) = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
 // ---- epilogues of the 32x32 kernels ------------------------------------------------------------------------
@@ -399,16 +360,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(GemmParams p) {
 // registers each).  Operand lane map: lane l holds A[row l&15][k = 8*(l>>4) .. +7] of a 16x32 block; C/D:
 // col = lane&15, row = 4*(lane>>4) + reg.  MI355X holds a higher clock on this shape under sustained MFMA load
 // (fc_0, same schedule, same box: 1.98 GHz and 968 k cycles against 1.84 GHz and 1003 k cycles on 32x32x16).
-typedef __attribute__((ext_vector_type(4))) float f32x4v;
-
-template <int FP16>
-__device__ __forceinline__ f32x4v mfma16(const bf16x8& a, const bf16x8& b, const f32x4v& c) {
-  if (FP16)
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b),
-                                                  c, 0, 0, 0);
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
-
 // staged epilogue of the 16x16 accumulator layout: 32 rows (two 16-row tiles) x 64 columns per turn; the 64
 // lanes of every ds_write_b32 hit 64 distinct banks (row stride 68 floats: +4 rows = +16 banks)
 template <typename F>

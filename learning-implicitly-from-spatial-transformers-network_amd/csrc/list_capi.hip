@@ -128,6 +128,35 @@ int64_t chunk_rows_for(size_t bytes, int64_t P, int Kp, int H1, int H2) {
   return fit >= kRowTile ? fit : 0;
 }
 
+// fc_0 with the perceptual block of its A operand produced on chip (fused_fc0_kernels.hip): fp16 operands and maps,
+// the per-point 2-D sample (no pre-pooled features, no projected map), H1 = 512.  LIST_FUSED_FC0 (environment, read
+// once): "0" keeps the unfused path (2-D gather kernel + k_gemm_nt_pp), "x" runs the 128 x 512 tile with every K-tile
+// from X (tile-shape diagnostic: the 2-D gather still runs).
+int fused_fc0_mode() {
+  static const int mode = [] {
+    const char* e = getenv("LIST_FUSED_FC0");
+#ifdef LIST_FUSED_FC0_DEFAULT_OFF
+    if (!e || !e[0]) return 0;
+#else
+    if (!e || !e[0]) return 1;
+#endif
+    if (e[0] == '0' && e[1] == 0) return 0;
+    if (e[0] == 'x') return 2;
+    return 1;
+  }();
+  return mode;
+}
+bool takes_fused_fc0_any(const ListQueryArgs* a, const FeatLayout& L) {
+  if (fused_fc0_mode() == 0) return false;
+  if (a->precision != LIST_PREC_FP16 || a->percep_feat || a->percep_proj || a->img_dtype != LIST_MAP_F16) return false;
+  return a->H1 == 512 && a->img_C > 0 && a->img_C % 64 == 0 && L.img_off == 0 && L.Kp % 64 == 0;
+}
+int fused_produced_tiles(const ListQueryArgs* a) { return fused_fc0_mode() == 2 ? 0 : a->img_C / 64; }
+// true: the 2-D gather kernel is NOT launched (its columns are produced inside fc_0)
+bool takes_fused_fc0(const ListQueryArgs* a, const FeatLayout& L) {
+  return takes_fused_fc0_any(a, L) && fused_fc0_mode() == 1;
+}
+
 // inference forwards in fp16: fc_1, fc_2 and fc_out as ONE launch (gemm_kernels.hip, k_mlp_tail_f16).  The one
 // predicate behind the dispatch in list_sdf_query_fwd and behind list_query_plan (what a caller's accounting reads).
 bool takes_fused_tail(const ListQueryArgs* a) {
@@ -423,7 +452,8 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
     }
     mark(LIST_STAGE_SORT);
     int* nan_tiles = (int*)(wsb + ws.nan_tiles);
-    e = launch_gather(g, L, chunk_args, nan_tiles, s);
+    const bool fused0 = takes_fused_fc0_any(a, L);            // the 128 x 512 kernel runs
+    e = launch_gather(g, L, chunk_args, nan_tiles, s, /*skip_img=*/takes_fused_fc0(a, L));
     if (e != hipSuccess) return hip_fail(e, "gather launch");
     mark(LIST_STAGE_TAIL);
 
@@ -454,7 +484,18 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
     // of those tiles are redone with the reference's skip semantics and fc_0 runs again for them.  On finite
     // inputs both gated launches exit at their first instruction.
     gp.nan_tiles = nan_tiles;
-    e = launch_gemm(gp, terms, EPI_RELU_SPLIT, s);
+    if (fused0) {
+      // the perceptual block of X is produced inside fc_0 (fused_fc0_kernels.hip): no 2-D gather launch above, those
+      // columns of X stay unwritten (the exact redo below rewrites them for the tiles it flags)
+      FusedFc0Params fp;
+      fp.gp = gp; fp.g = g; fp.img_map = a->img_map; fp.trans_mat = a->trans_mat;
+      fp.ms = a->map_size; fp.Ct = a->img_C; fp.clamp_hi = a->clamp_hi; fp.n_produced = fused_produced_tiles(a);
+      if (!fused_fc0_eligible(gp, a->img_dtype == LIST_MAP_F16, a->img_C))
+        return fail(LIST_ERR_ARG, "internal: fused fc_0 taken for arguments it does not support");
+      e = launch_fc0_fused(fp, s);
+    } else {
+      e = launch_gemm(gp, terms, EPI_RELU_SPLIT, s);
+    }
     if (e != hipSuccess) return hip_fail(e, "fc_0 launch");
     mark(LIST_STAGE_FC0);
     e = launch_gather_fixup(g, L, chunk_args, nan_tiles, s);
@@ -526,6 +567,7 @@ int list_query_plan(const ListQueryArgs* a, ListQueryPlan* plan) {
     const int n_valid = (int)(P < rows ? P : rows);
     const GatherParams g = make_gather(a, L, ws, 0, n_valid, (n_valid + kRowTile - 1) / kRowTile * kRowTile);
     plan->box_levels = gather_box_levels(g, L, *a);
+    plan->fused_fc0 = takes_fused_fc0(a, L) ? 1 : 0;
   }
   return LIST_OK;
 }

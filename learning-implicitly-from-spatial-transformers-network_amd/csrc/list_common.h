@@ -446,8 +446,9 @@ struct SortBuffers { int* order; int* order_img; int* row_of; int* keys; int* ke
 hipError_t launch_sort_points(const GatherParams& g, const ListQueryArgs& a, const SortBuffers& sb,
                               hipStream_t s);
 // nan_tiles: int32 [rows / 256], cleared by the last gather kernel (the flags of fc_0's NaN probe)
+// skip_img: the 2-D gather is left out (its columns of X are produced inside the fused fc_0, fused_fc0_kernels.hip)
 hipError_t launch_gather(const GatherParams& g, const FeatLayout& L, const ListQueryArgs& a,
-                         int* nan_tiles, hipStream_t s);
+                         int* nan_tiles, hipStream_t s, bool skip_img = false);
 hipError_t launch_features_out(const GatherParams& g, const FeatLayout& L, float* out, int* nan_tiles,
                                hipStream_t s);
 // coarse levels on the matrix cores (gather_box_kernels.hip); eligible: near level, C = 128, fp16 maps and fp16 X
@@ -459,6 +460,18 @@ hipError_t launch_gather_fixup(const GatherParams& g, const FeatLayout& L, const
                                const int* tile_flags, hipStream_t s);
 hipError_t launch_percep_pool(const ListPoolArgs& a, hipStream_t s);
 hipError_t launch_gemm(const GemmParams& p, int terms, int epi, hipStream_t s);
+// fc_0 on a 128 x 512 tile with the perceptual block of A produced on chip (fused_fc0_kernels.hip)
+struct FusedFc0Params {
+  GemmParams gp;                 // a_hi = X [M][K], w_hi = packed W0 [512][K], bias, M (% 128 == 0), N = 512, K (% 64 == 0),
+                                 //   out_hi = H1, ldo, nan_tiles
+  GatherParams g;                // the points behind the rows (query, order, perm, scale, N, p_begin, n_valid)
+  const void* img_map;           // prepared map [B][ms][ms][Ct] fp16
+  const float* trans_mat;        // [B][4][3]
+  int ms, Ct; float clamp_hi;
+  int n_produced;                // leading K-tiles produced on chip (Ct / 64); 0: every K-tile from X (tile-shape diagnostic)
+};
+bool fused_fc0_eligible(const GemmParams& gp, int img_f16, int img_C);
+hipError_t launch_fc0_fused(const FusedFc0Params& fp, hipStream_t s);
 // fc_1 + fc_2 + fc_out in one launch (fp16 operands, H2 = H3 = 256, nothing kept for a backward): gemm_kernels.hip
 hipError_t launch_mlp_tail(const GemmParams& fc1, const char* w2, const float* b2, const float* w3, const float* b3,
                            float* sdf, const int* order, int n_valid, hipStream_t s);

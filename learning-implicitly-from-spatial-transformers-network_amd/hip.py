@@ -120,7 +120,8 @@ class ListPoolGradArgs(C.Structure):
 
 class ListQueryPlan(C.Structure):
     _fields_ = [("rows_per_chunk", C.c_int64), ("chunks", C.c_int32), ("fused_tail", C.c_int32),
-                ("fc0_k", C.c_int32), ("box_levels", C.c_int32), ("reserved_", C.c_int32 * 2)]
+                ("fc0_k", C.c_int32), ("box_levels", C.c_int32), ("fused_fc0", C.c_int32),
+                ("reserved_", C.c_int32 * 1)]
 
 
 EXPORTS = {
@@ -477,6 +478,11 @@ def query_chunks(n_points, packed):
     return (n_points + rows - 1) // rows
 
 
+# diagnostics (bench.py --whole-model): a ctypes array of hipEvent_t handles (N_STAGES per row chunk) recorded by the
+# next inference queries that pass no stage_events of their own -- the stage times INSIDE LIST.forward
+STAGE_EVENTS_HOOK = None
+
+
 class QueryContext:
     """What list_sdf_query_bwd needs from a forward call: its argument block (pointers into tensors
     kept alive here) including the private workspace."""
@@ -513,6 +519,8 @@ def sdf_query(query, trans_mat, img, vox, packed, perm=(2, 1, 0), scale=2.0, pre
             raise RuntimeError("percep_proj was made from another prepared map or other packed weights")
         a.percep_proj = percep_proj.data.data_ptr()
         keep.append(percep_proj)
+    if stage_events is None and STAGE_EVENTS_HOOK is not None and not save_for_backward:
+        stage_events = STAGE_EVENTS_HOOK     # diagnostics: stage times of calls made through the module API (bench.py)
     if stage_events is not None:
         a.stage_events = C.cast(stage_events, C.POINTER(C.c_void_p))
         a.stage_event_sets = max(1, len(stage_events) // N_STAGES)
@@ -525,7 +533,7 @@ def sdf_query(query, trans_mat, img, vox, packed, perm=(2, 1, 0), scale=2.0, pre
         pl = ListQueryPlan()
         _check(lib.list_query_plan(C.byref(a), C.byref(pl)), "list_query_plan")
         plan.update(chunks=pl.chunks, rows_per_chunk=pl.rows_per_chunk, fused_tail=pl.fused_tail, fc0_k=pl.fc0_k,
-                    box_levels=pl.box_levels)
+                    box_levels=pl.box_levels, fused_fc0=pl.fused_fc0)
     with torch.cuda.device(query.device):
         _check(lib.list_sdf_query_fwd(C.byref(a), _stream()), "list_sdf_query_fwd")
     if save_for_backward:
