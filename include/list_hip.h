@@ -199,7 +199,10 @@ typedef struct ListQueryArgs {
                                         /*   then run as ONE kernel that keeps H2 in registers (fp16 */
                                         /*   operands, H2 = H3 = 256; other cases: no effect).  The  */
                                         /*   values are those of the two-launch path bit for bit     */
-                                        /*   (same products, k order and summation tree).  0         */
+                                        /*   (same products, k order and summation tree).  Such a    */
+                                        /*   forward may also leave columns of the feature matrix    */
+                                        /*   unwritten (ABI 7: the perceptual block is produced      */
+                                        /*   inside fc_0, list_query_plan().fused_fc0).  0           */
                                         /*   (default): H1, H2, H3 are left in the workspace for the */
                                         /*   backward.  list_sdf_query_bwd refuses (LIST_ERR_ARG) a  */
                                         /*   forward that had it set.                                */

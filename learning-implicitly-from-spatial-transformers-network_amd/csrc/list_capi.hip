@@ -149,6 +149,9 @@ int fused_fc0_mode() {
 bool takes_fused_fc0_any(const ListQueryArgs* a, const FeatLayout& L) {
   if (fused_fc0_mode() == 0) return false;
   if (a->precision != LIST_PREC_FP16 || a->percep_feat || a->percep_proj || a->img_dtype != LIST_MAP_F16) return false;
+  // inference forwards only: list_sdf_query_bwd reads the WHOLE feature matrix (d fc_0.weight = dZ1^T . X, the perceptual
+  // columns included), so a forward that a backward may follow materialises it
+  if (!a->no_activations) return false;
   return a->H1 == 512 && a->img_C > 0 && a->img_C % 64 == 0 && L.img_off == 0 && L.Kp % 64 == 0;
 }
 int fused_produced_tiles(const ListQueryArgs* a) { return fused_fc0_mode() == 2 ? 0 : a->img_C / 64; }

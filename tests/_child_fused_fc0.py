@@ -29,8 +29,10 @@ def run(hip, c, res, tag, map_size=137, clamp_hi=136.0, sorts=(True, False), tra
         res[f"{tag}_{'sorted' if sort else 'unsorted'}"] = sdf.cpu().numpy()
         res[f"{tag}_fused_fc0"] = np.int32(plan["fused_fc0"])
     if train:       # a forward that keeps its activations (two-launch tail, H1 / H2 / H3 in the workspace)
-        sdf, _ = hip.sdf_query(q, T, img, vox, packed, precision="fp16", clamp_hi=clamp_hi, save_for_backward=True)
+        plan = {}
+        sdf, _ = hip.sdf_query(q, T, img, vox, packed, precision="fp16", clamp_hi=clamp_hi, save_for_backward=True, plan=plan)
         res[f"{tag}_train"] = sdf.cpu().numpy()
+        res[f"{tag}_train_plan_fused_fc0"] = np.int32(plan["fused_fc0"])
 
 
 def main(out_path, full):

@@ -29,6 +29,7 @@ def _run(tmp_path, tag, mode, full):
 def _same(a, b, what):
     keys = sorted(k for k in a.files if not k.endswith("_fused_fc0"))
     assert keys == sorted(k for k in b.files if not k.endswith("_fused_fc0"))
+    assert len(keys) >= 10
     for k in keys:
         x, y = a[k], b[k]
         # bit for bit, NaN positions included (array_equal treats NaN as unequal: compare the raw bits)
@@ -40,6 +41,9 @@ def test_fused_fc0_equals_the_unfused_path_bit_for_bit(tmp_path):
     plain = _run(str(tmp_path), "off", "0", True)
     assert int(fused["config2_fused_fc0"]) == 1 and int(plain["config2_fused_fc0"]) == 0     # (what the library dispatched)
     assert int(fused["tiny_fused_fc0"]) == 1
+    # a forward that keeps its activations for list_sdf_query_bwd materialises the whole feature matrix (d fc_0.weight
+    # reads its perceptual columns): never the fused kernel
+    assert int(fused["small_train_plan_fused_fc0"]) == 0
     _same(fused, plain, "fused vs unfused")
     assert np.isfinite(fused["config2_sorted"]).all() and np.abs(fused["config2_sorted"]).max() > 1e-3
 
