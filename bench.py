@@ -154,13 +154,6 @@ def kernel_table(B, N, img_res, vox_res, map_size, x_bytes_per_feature, map_byte
 # asynchronous all-gather, exchange check, rank census): the RCCL pre-flight on a one-GPU box
 # (tests/test_rccl_preflight_gpu.py, with LIST_FORCE_COLLECTIVES=1 for list_amd.parallel).  Never a scaling number.
 FORCE_EXCHANGE = os.environ.get("LIST_BENCH_FORCE_EXCHANGE", "0") == "1"
-PREP_FORK = os.environ.get("LIST_BENCH_PREP_FORK", "0") != "0"
-_side = {}
-def _side_stream(device):
-    import torch
-    if device not in _side:
-        _side[device] = torch.cuda.Stream(device)
-    return _side[device]
 
 
 def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gather_fn, sustained_steps=0):
@@ -208,21 +201,10 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
             pending[k] = None
         if pre: ev.record(pre[0])
         md = hip.map_dtype_for(precision)
-        if PREP_FORK:
-            # EXPERIMENT (round 4): the resize of the 2-D maps on a side stream beside the 3-D layout hand-off
-            cur = torch.cuda.current_stream()
-            side = _side_stream(device)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                img = hip.prep_img_maps(inp["img_maps"], inp["map_size"], md)
-            vox = hip.prep_vox_maps(inp["vox_maps"], md)
-            cur.wait_stream(side)
-            if pre: ev.record(pre[1]); ev.record(pre[2])
-        else:
-            img = hip.prep_img_maps(inp["img_maps"], inp["map_size"], md)
-            if pre: ev.record(pre[1])
-            vox = hip.prep_vox_maps(inp["vox_maps"], md)
-            if pre: ev.record(pre[2])
+        img = hip.prep_img_maps(inp["img_maps"], inp["map_size"], md)
+        if pre: ev.record(pre[1])
+        vox = hip.prep_vox_maps(inp["vox_maps"], md)
+        if pre: ev.record(pre[2])
         packed = hip.prep_mlp_weights(inp["weights"], vox.channels, img.channels, precision)
         # inference grid (executors.LIST.predict_grid): many points on one image -- the perceptual block of fc_0 is
         # applied to the 137^2 map once (inside the timed step, counted with prep_weights) and sampled per point
@@ -305,6 +287,9 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
         kernel_ms["fc_2_out"] += kernel_ms["fc_1"]
         kernel_ms["fc_1"] = 0.0
         kernel_ms["_fused_tail"] = 1
+    if plan.get("fused_fc0"):
+        # fc_0 produced the perceptual block of its A operand on chip (k_fc0_fused): no 2-D gather kernel ran
+        kernel_ms["_fused_fc0"] = 1
     kernel_ms["gathers_back_to_back"] = group / steps       # the same seven launches as they run in the timed region
     kernel_ms["gathers_one_by_one_sum"] = float(sum(acc[3 + s] for s in range(first, hip.STAGE_IMG + 1)))   # (untimed steps)
     kernel_ms["_launches_per_step"] = n_chunks
@@ -569,7 +554,9 @@ def roofline_of(kernel_ms, table, precision, workload, batch):
     # fc_0 runs the ping-pong schedule in every precision (single plane, or hi / lo interleaved for the split formats)
     fc1 = "k_gemm_nt (fc_1 + ReLU)" if precision == "bf16x3" else "k_gemm_nt_pp (fc_1 + ReLU)"
     tail = "k_mlp_tail_f16 (fc_1 + ReLU + fc_2 + ReLU + fc_out)" if kernel_ms.get("_fused_tail") else "k_gemm_nt16 (fc_2 + ReLU + fc_out)"
-    r = {"kernel": {"fc_0": "k_gemm_nt_pp (fc_0 + ReLU)", "fc_1": fc1, "fc_2_out": tail}[dom],
+    fc0 = ("k_fc0_fused (bilinear sample of the perceptual block into LDS + fc_0 + ReLU; the FLOPs are fc_0's)"
+           if kernel_ms.get("_fused_fc0") else "k_gemm_nt_pp (fc_0 + ReLU)")
+    r = {"kernel": {"fc_0": fc0, "fc_1": fc1, "fc_2_out": tail}[dom],
          "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
          "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "launches_per_step": launches,
          "launch_ms": kernel_ms[dom] / launches, "algorithmic_flop_per_launch": units / launches,
@@ -779,6 +766,17 @@ def main():
         t3, _ = run_train_step("bf16x3", max(2, args.steps // 4), min(args.warmup, 2), inp, hip, ev)
         train["fp32_grade"] = {k: t3[k] for k in ("precision", "steps", "ms_per_step", "value", "forward_query_ms",
                                                   "backward_ms", "kernel_ms", "kernel_ms_inline", "roofline")}
+        # the same step with projections piled onto the clamp of network/modules.py:43, the regime training STARTS in (an
+        # untrained spatial transformer: 88 % of the points, --whole-model): u, v spread 8x wider around the map centre
+        inp_p = dict(inp)
+        Tp = inp["trans_mat"].clone()
+        Tp[:, :3, :2] *= 8.0
+        inp_p["trans_mat"] = Tp
+        tp, _ = run_train_step(headline, max(2, args.steps // 4), min(args.warmup, 2), inp_p, hip, ev)
+        train["piled_on_clamp"] = {"frac_points_on_clamp": float(_on_clamp(inp["query"], Tp)), "ms_per_step": tp["ms_per_step"],
+                                   "backward_ms": tp["backward_ms"], "img_map_grad_ms_inline": tp["kernel_ms_inline"]["img_map_grad"],
+                                   "note": "map-side gather of the perceptual-map gradient with its heavy pixel groups cut "
+                                           "into chunks (round 4); 8.7 ms / 2.58 ms before"}
         train["gradient_precision_note"] = (
             "fp16 operands flip ~1e-3 of the ReLU masks: gradients carry 2-4 % relative L2 noise against the "
             "reference's autograd (grad_rel_l2_vs_cpu); the bf16x3 step reproduces them to 1.5e-5 of each tensor's "

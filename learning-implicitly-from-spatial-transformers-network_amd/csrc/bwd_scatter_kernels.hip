@@ -12,6 +12,7 @@
 // and for the perceptual map no atomics at all: the points are already in pixel order (forward's second
 // sort), so every map pixel GATHERS the contributions of the <= 4 pixel cells around it and is written once.
 #include <limits.h>
+#include <string.h>
 
 #include "list_common.h"
 #include "point_math.h"
@@ -860,7 +861,157 @@ __global__ __launch_bounds__(256) void k_img_records(GatherParams g, const float
 // One workgroup per (image, map row Y, group of 4 map columns); thread t owns channels 4t .. 4t+3 (and
 // +1024 ...).  Candidates = the points of the <= 4 pixel cells (rows Y-1, Y; column groups cx-1, cx)
 // whose 2x2 footprint can reach the group; each contributes w(tap) * dX[row][img_off + c].
+//
+// Heavy groups (round 4).  Projections that pile onto the clamp of network/modules.py:43 -- an untrained spatial
+// transformer puts ~90 % of the points there -- fill a handful of border cells with tens of thousands of candidates,
+// which ONE workgroup then walked one after the other (measured: this stage 0.36 -> 2.58 ms at 98 % of the points on the
+// clamp, the training step 6.7 -> 8.7 ms).  A group with more than kHeavyChunk candidates is therefore cut into chunks of
+// kHeavyChunk: k_img_heavy_plan numbers the chunks (one scan over the groups), k_img_heavy_partial sums each chunk in its
+// own workgroup into a partial row, and the group's own workgroup adds the partial rows in chunk order instead of
+// walking the candidates (no atomics: as reproducible as before).
 constexpr int kImgCand = 128;
+constexpr int kHeavyChunk = 1024;
+
+__device__ __forceinline__ void img_group_cells(const int* __restrict__ bins, int slot_img, int Y, int cx, int cw,
+                                                int (&beg)[4], int (&end)[4]) {
+  // candidate slot ranges of the 4 cells (bins hold END offsets after the forward's scatter pass)
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int yy = Y - 1 + (k >> 1), cc = cx - 1 + (k & 1);
+    beg[k] = end[k] = 0;
+    if (yy < 0 || cc < 0) continue;
+    const int bin = slot_img * kSortPixCells + min(yy * cw + cc, kSortPixCells - 1);
+    beg[k] = bin > 0 ? bins[bin - 1] : 0;
+    end[k] = bins[bin];
+  }
+}
+
+// candidates [s_begin, s_end) of the record array: acc[t][e] += w(tap of map column X0 + t, row Y) * dX[row][c + e]
+template <int DXH>
+__device__ __forceinline__ void img_accumulate(const ScatterParams& sp, const ImgRec* __restrict__ recs, ImgRec* cand,
+                                               int s_begin, int s_end, int b, int Y, int X0, int qd, int nq,
+                                               int img_off, float (&acc)[4][4]) {
+  for (int s0 = s_begin; s0 < s_end; s0 += kImgCand) {
+    const int n = min(kImgCand, s_end - s0);
+    __syncthreads();
+    if ((int)threadIdx.x < n) cand[threadIdx.x] = recs[s0 + threadIdx.x];
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+      const ImgRec r = cand[i];
+      if (r.b != b) continue;                            // a clamped bin index may mix images: never, but cheap
+      const float wy = (r.y0 == Y) ? r.wy0 : ((r.y0 + 1 == Y) ? r.wy1 : 0.f);
+      if ((r.y0 != Y && r.y0 + 1 != Y) || r.x0 + 1 < X0 || r.x0 > X0 + 3) continue;
+      if (qd >= nq) continue;
+      float gv[4];
+      const int64_t o = (int64_t)r.row * sp.g.Kp + img_off + qd * 4;
+      if (DXH) {
+        const uint2 h = *(const uint2*)((const unsigned short*)sp.dx + o);
+        gv[0] = h2f((unsigned short)(h.x & 0xffff)); gv[1] = h2f((unsigned short)(h.x >> 16));
+        gv[2] = h2f((unsigned short)(h.y & 0xffff)); gv[3] = h2f((unsigned short)(h.y >> 16));
+      } else {
+        const float4 f = *(const float4*)((const float*)sp.dx + o);
+        gv[0] = f.x; gv[1] = f.y; gv[2] = f.z; gv[3] = f.w;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int X = X0 + t;
+        const float wx = (r.x0 == X) ? r.wx0 : ((r.x0 + 1 == X) ? r.wx1 : 0.f);
+        const float w = wx * wy;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][e] = fmaf(w, gv[e], acc[t][e]);
+      }
+    }
+  }
+}
+
+// chunk bookkeeping of the heavy groups (device memory in the backward workspace)
+struct ImgHeavy {
+  int* total;            // [1] chunks in use
+  int* group_base;       // [groups] first chunk of a heavy group, -1: light
+  int* chunk_group;      // [max_chunks]
+  int* chunk_index;      // [max_chunks] index of the chunk inside its group
+  float* partial;        // [max_chunks][4][Ct]
+  int max_chunks;
+};
+
+// 1024 groups per workgroup: S_g = ceil(n_g / kHeavyChunk) for groups above kHeavyChunk candidates; a workgroup that
+// holds such groups scans their S_g and takes a run of chunk slots from the global counter (*h.total, zeroed by the
+// launcher; the runs need no particular order).  Without heavy groups -- the usual case -- it leaves after one barrier.
+__global__ __launch_bounds__(1024) void k_img_heavy_plan(const int* __restrict__ bins, int b_first, int B, int ms,
+                                                         ImgHeavy h) {
+  __shared__ int part[1024];
+  __shared__ int run_base;
+  const int cw = (ms + 3) / 4;
+  const int groups = B * ms * cw;
+  const int g = blockIdx.x * 1024 + threadIdx.x;
+  int S = 0;
+  if (g < groups) {
+    const int cx = g % cw, Y = (g / cw) % ms, b = g / (cw * ms);
+    int beg[4], end[4];
+    img_group_cells(bins, (b - b_first) % kSortImages, Y, cx, cw, beg, end);
+    const int n = (end[0] - beg[0]) + (end[1] - beg[1]) + (end[2] - beg[2]) + (end[3] - beg[3]);
+    S = n > kHeavyChunk ? (n + kHeavyChunk - 1) / kHeavyChunk : 0;
+  }
+  if (!__syncthreads_or(S > 0)) {
+    if (g < groups) h.group_base[g] = -1;
+    return;
+  }
+  part[threadIdx.x] = S;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  if (threadIdx.x == 1023) run_base = atomicAdd(h.total, part[1023]);
+  __syncthreads();
+  if (g >= groups) return;
+  const int base = run_base + part[threadIdx.x] - S;
+  const bool fits = S > 0 && base + S <= h.max_chunks;         // (the layout's bound holds all of them; belt and braces)
+  h.group_base[g] = fits ? base : -1;
+  // (every slot below min(*total, max_chunks) names a valid group, fitting or not: the partial kernel reads group_base)
+  for (int i = 0; i < S && base + i < h.max_chunks; ++i) { h.chunk_group[base + i] = g; h.chunk_index[base + i] = i; }
+}
+
+// one workgroup per chunk slot: the partial sums of candidates [ci * kHeavyChunk, (ci + 1) * kHeavyChunk) of the group's
+// four cells taken as one list
+template <int DXH>
+__global__ __launch_bounds__(256) void k_img_heavy_partial(ScatterParams sp, const ImgRec* __restrict__ recs,
+                                                           const int* __restrict__ bins, int b_first, int ms, int Ct,
+                                                           int img_off, ImgHeavy h) {
+  __shared__ ImgRec cand[kImgCand];
+  const int slot = blockIdx.x;
+  if (slot >= min(*h.total, h.max_chunks)) return;
+  const int g = h.chunk_group[slot], ci = h.chunk_index[slot];
+  if (h.group_base[g] < 0) return;                               // (a run that did not fit: its group walks its candidates)
+  const int cw = (ms + 3) / 4;
+  const int cx = g % cw, Y = (g / cw) % ms, b = g / (cw * ms);
+  int beg[4], end[4];
+  img_group_cells(bins, (b - b_first) % kSortImages, Y, cx, cw, beg, end);
+  const int nq = Ct / 4;
+  const int lo = ci * kHeavyChunk, hi = lo + kHeavyChunk;           // positions in the concatenated candidate list
+  for (int q0 = 0; q0 < nq; q0 += 256) {
+    const int qd = q0 + threadIdx.x;
+    float acc[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
+    int pos = 0;
+    for (int k = 0; k < 4; ++k) {
+      const int len = end[k] - beg[k];
+      const int a0 = max(lo - pos, 0), a1 = min(hi - pos, len);
+      if (a0 < a1) img_accumulate<DXH>(sp, recs, cand, beg[k] + a0, beg[k] + a1, b, Y, 4 * cx, qd, nq, img_off, acc);
+      pos += len;
+    }
+    if (qd < nq) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        *(float4*)(h.partial + ((int64_t)slot * 4 + t) * Ct + qd * 4) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    }
+  }
+}
 
 // GH (fp16 operands only): the map gradient is the intermediate of the adjoint resize in the same call -- written as
 // halfs AT the gradient scale s (the sums of a pixel's <= 4 cells of s * dX values: saturating conversion), and
@@ -868,7 +1019,7 @@ constexpr int kImgCand = 128;
 template <int DXH, int GH = 0>
 __global__ __launch_bounds__(256) void k_img_grad_gather(ScatterParams sp, const ImgRec* __restrict__ recs,
                                                          const int* __restrict__ bins, int b_first, int ms,
-                                                         int Ct, int img_off, float* __restrict__ out) {
+                                                         int Ct, int img_off, float* __restrict__ out, ImgHeavy h) {
   __shared__ ImgRec cand[kImgCand];
   const int cw = (ms + 3) / 4;
   const int cx = blockIdx.x % cw;
@@ -879,17 +1030,10 @@ __global__ __launch_bounds__(256) void k_img_grad_gather(ScatterParams sp, const
   const float inv_s = sp.scale[1];
   const int nq = Ct / 4;                                   // channel quads
 
-  // candidate slot ranges of the 4 cells (bins hold END offsets after the forward's scatter pass)
   int beg[4], end[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int yy = Y - 1 + (k >> 1), cc = cx - 1 + (k & 1);
-    beg[k] = end[k] = 0;
-    if (yy < 0 || cc < 0) continue;
-    const int bin = slot_img * kSortPixCells + min(yy * cw + cc, kSortPixCells - 1);
-    beg[k] = bin > 0 ? bins[bin - 1] : 0;
-    end[k] = bins[bin];
-  }
+  img_group_cells(bins, slot_img, Y, cx, cw, beg, end);
+  const int hbase = h.group_base ? h.group_base[blockIdx.x] : -1;
+  const int n_all = (end[0] - beg[0]) + (end[1] - beg[1]) + (end[2] - beg[2]) + (end[3] - beg[3]);
   float acc[4][4];
   for (int q0 = 0; q0 < nq; q0 += 256) {
     const int qd = q0 + threadIdx.x;
@@ -897,38 +1041,19 @@ __global__ __launch_bounds__(256) void k_img_grad_gather(ScatterParams sp, const
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
-    for (int k = 0; k < 4; ++k) {
-      for (int s0 = beg[k]; s0 < end[k]; s0 += kImgCand) {
-        const int n = min(kImgCand, end[k] - s0);
-        __syncthreads();
-        if ((int)threadIdx.x < n) cand[threadIdx.x] = recs[s0 + threadIdx.x];
-        __syncthreads();
-        for (int i = 0; i < n; ++i) {
-          const ImgRec r = cand[i];
-          if (r.b != b) continue;                            // a clamped bin index may mix images: never, but cheap
-          const float wy = (r.y0 == Y) ? r.wy0 : ((r.y0 + 1 == Y) ? r.wy1 : 0.f);
-          if ((r.y0 != Y && r.y0 + 1 != Y) || r.x0 + 1 < X0 || r.x0 > X0 + 3) continue;
-          if (qd >= nq) continue;
-          float gv[4];
-          const int64_t o = (int64_t)r.row * sp.g.Kp + img_off + qd * 4;
-          if (DXH) {
-            const uint2 h = *(const uint2*)((const unsigned short*)sp.dx + o);
-            gv[0] = h2f((unsigned short)(h.x & 0xffff)); gv[1] = h2f((unsigned short)(h.x >> 16));
-            gv[2] = h2f((unsigned short)(h.y & 0xffff)); gv[3] = h2f((unsigned short)(h.y >> 16));
-          } else {
-            const float4 f = *(const float4*)((const float*)sp.dx + o);
-            gv[0] = f.x; gv[1] = f.y; gv[2] = f.z; gv[3] = f.w;
-          }
+    if (hbase >= 0) {
+      // heavy group: its chunks were summed by k_img_heavy_partial; add the partial rows in chunk order
+      const int S = (n_all + kHeavyChunk - 1) / kHeavyChunk;
+      if (qd < nq)
+        for (int i = 0; i < S; ++i)
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            const int X = X0 + t;
-            const float wx = (r.x0 == X) ? r.wx0 : ((r.x0 + 1 == X) ? r.wx1 : 0.f);
-            const float w = wx * wy;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[t][e] = fmaf(w, gv[e], acc[t][e]);
+            const float4 v = *(const float4*)(h.partial + ((int64_t)(hbase + i) * 4 + t) * Ct + qd * 4);
+            acc[t][0] += v.x; acc[t][1] += v.y; acc[t][2] += v.z; acc[t][3] += v.w;
           }
-        }
-      }
+    } else {
+      for (int k = 0; k < 4; ++k)
+        img_accumulate<DXH>(sp, recs, cand, beg[k], end[k], b, Y, X0, qd, nq, img_off, acc);
     }
     if (qd < nq) {
 #pragma unroll
@@ -1123,7 +1248,8 @@ __global__ __launch_bounds__(256) void k_trans_grad(ScatterParams sp, const void
 
 hipError_t launch_img_grad(const ScatterParams& sp, const FeatLayout& L, const ListQueryArgs& a,
                            const int* bins_pix, int nslots, void* recs, float* grad_img_map, int map_f16,
-                           float* grad_trans_mat, void* const* stage_events, hipStream_t s) {
+                           float* grad_trans_mat, void* const* stage_events, hipStream_t s, void* heavy,
+                           size_t heavy_bytes) {
   (void)nslots;
   const int ms = a.map_size, Ct = L.img_C;
   ImgRec* rc = (ImgRec*)recs;
@@ -1136,17 +1262,44 @@ hipError_t launch_img_grad(const ScatterParams& sp, const FeatLayout& L, const L
     const int B = (int)((sp.g.p_begin + sp.g.n_valid + sp.g.N - 1) / sp.g.N);
     if (sp.g.order_img && bins_pix) {
       const dim3 grid((unsigned)(B * ms * ((ms + 3) / 4)));
+      const int b_first = (int)(sp.g.p_begin / sp.g.N);
+      // heavy groups first (scratch carved from `heavy`: [total | group_base | chunk_group | chunk_index | partial rows])
+      ImgHeavy h;
+      memset(&h, 0, sizeof(h));
+      if (heavy && heavy_bytes >= img_heavy_bytes(sp.g.rows, Ct)) {
+        char* hb = (char*)heavy;
+        h.max_chunks = img_heavy_max_chunks(sp.g.rows);
+        h.total = (int*)hb; hb += 256;
+        h.group_base = (int*)hb; hb += (size_t)kSortImages * kSortPixCells * 4;
+        h.chunk_group = (int*)hb; hb += (size_t)h.max_chunks * 4;
+        h.chunk_index = (int*)hb; hb += (size_t)h.max_chunks * 4;
+        hb = (char*)(((uintptr_t)hb + 255) & ~(uintptr_t)255);
+        h.partial = (float*)hb;
+        if ((size_t)grid.x <= (size_t)kSortImages * kSortPixCells) {
+          hipError_t ez = hipMemsetAsync(h.total, 0, sizeof(int), s);
+          if (ez != hipSuccess) return ez;
+          hipLaunchKernelGGL(k_img_heavy_plan, dim3((grid.x + 1023) / 1024), dim3(1024), 0, s, bins_pix, b_first, B, ms, h);
+          if (sp.dx_f16)
+            hipLaunchKernelGGL(k_img_heavy_partial<1>, dim3((unsigned)h.max_chunks), dim3(256), 0, s, sp, rc, bins_pix, b_first,
+                               ms, Ct, L.img_off, h);
+          else
+            hipLaunchKernelGGL(k_img_heavy_partial<0>, dim3((unsigned)h.max_chunks), dim3(256), 0, s, sp, rc, bins_pix, b_first,
+                               ms, Ct, L.img_off, h);
+        } else {
+          h.group_base = nullptr;
+        }
+      }
       if (sp.dx_f16 && map_f16)
-        hipLaunchKernelGGL((k_img_grad_gather<1, 1>), grid, dim3(256), 0, s, sp, rc, bins_pix, (int)(sp.g.p_begin / sp.g.N),
-                           ms, Ct, L.img_off, grad_img_map);
+        hipLaunchKernelGGL((k_img_grad_gather<1, 1>), grid, dim3(256), 0, s, sp, rc, bins_pix, b_first,
+                           ms, Ct, L.img_off, grad_img_map, h);
       else if (map_f16)
         return hipErrorInvalidValue;
       else if (sp.dx_f16)
-        hipLaunchKernelGGL(k_img_grad_gather<1>, grid, dim3(256), 0, s, sp, rc, bins_pix, (int)(sp.g.p_begin / sp.g.N),
-                           ms, Ct, L.img_off, grad_img_map);
+        hipLaunchKernelGGL(k_img_grad_gather<1>, grid, dim3(256), 0, s, sp, rc, bins_pix, b_first,
+                           ms, Ct, L.img_off, grad_img_map, h);
       else
-        hipLaunchKernelGGL(k_img_grad_gather<0>, grid, dim3(256), 0, s, sp, rc, bins_pix, (int)(sp.g.p_begin / sp.g.N),
-                           ms, Ct, L.img_off, grad_img_map);
+        hipLaunchKernelGGL(k_img_grad_gather<0>, grid, dim3(256), 0, s, sp, rc, bins_pix, b_first,
+                           ms, Ct, L.img_off, grad_img_map, h);
     } else {
       if (map_f16) return hipErrorInvalidValue;            // (list_capi.hip rejects the combination)
       hipError_t e = hipMemsetAsync(grad_img_map, 0, (size_t)B * ms * ms * Ct * sizeof(float), s);

@@ -15,7 +15,9 @@
 // accumulator registers).  LDS 160 KB: W 2 x 64 KB, A 2 x 16 KB; rows of 128 B, 16-B chunks XOR-swizzled with (row>>1)&7
 // (on the LDS-DMA source address / the ds_write address, and on the ds_read_b128 address) as in gemm_kernels.hip.
 // Same MFMA, same operand roles and the same k order per output element as k_gemm_nt_pp: bit-identical to the unfused
-// path (tests/test_fused_fc0_gpu.py).  The NaN probe / exact redo of flagged 256-row tiles is unchanged: the fix-up
+// path (tests/test_fused_fc0_gpu.py).  X3 = 3 / 1: the bf16 split formats (operand rows of 32 hi + 32 lo halfs per
+// 32-column K-tile, list_common.h xi_off; fp32 maps; three MFMAs per operand pair in k_gemm_nt_pp's order, or hi . hi
+// alone for plain bf16).  The NaN probe / exact redo of flagged 256-row tiles is unchanged: the fix-up
 // kernel rewrites the whole X row of such tiles (perceptual block included) and the gated k_gemm_nt_pp re-runs on it.
 #include "list_common.h"
 #include "mfma_common.h"
@@ -34,8 +36,11 @@ __device__ __forceinline__ int fswz(int row) { return (row >> 1) & 7; }
 // per-thread record of one row's projection (project(), point_math.h), packed: what the four tap loads need
 struct RowProj { int64_t base; int dx, dy; float w00, w01, w10, w11; int valid; };
 
+template <int X3>
 __global__ __launch_bounds__(512, 2) void k_fc0_fused(FusedFc0Params fp) {
-  using M = MapT<1>;
+  constexpr bool F16 = X3 == 0;
+  constexpr int KT = F16 ? 64 : 32;                 // feature columns per K-tile (128 operand bytes per row)
+  using M = MapT<F16 ? 1 : 0>;
   __shared__ __attribute__((aligned(16))) char smem[kFusedLds];
   const GemmParams& p = fp.gp;
   const int tid = threadIdx.x;
@@ -44,11 +49,11 @@ __global__ __launch_bounds__(512, 2) void k_fc0_fused(FusedFc0Params fp) {
   const int wm = wave >> 2, wn = wave & 3;
   const int ntiles = p.M / 128;
   const int m0 = xcd_contiguous_block(blockIdx.x, ntiles) * 128;
-  const int nk = p.K / 64;
+  const int nk = p.K / KT;
   const int np = fp.n_produced;
-  const int64_t lda = (int64_t)p.K * 2, ldw = (int64_t)p.K * 2;
+  const int64_t lda = (int64_t)p.K * (F16 ? 2 : 4), ldw = lda;      // bytes per operand row (hi + lo interleaved)
 
-  // ---- the two items of this thread in a produced K-tile: rows r0, r0 + 64, chunk c (8 channels = 16 B)
+  // ---- the two items of this thread in a produced K-tile: rows r0, r0 + 64, chunk c (16 B of map: 8 halfs / 4 floats)
   const int pc = tid & 7, pr = tid >> 3;
   RowProj rp[2];
   if (np > 0) {
@@ -56,17 +61,17 @@ __global__ __launch_bounds__(512, 2) void k_fc0_fused(FusedFc0Params fp) {
     for (int h = 0; h < 2; ++h) {
       const Pt pt = load_point(fp.g, m0 + pr + 64 * h);
       const Proj q = project(fp.trans_mat + pt.b * 12, pt.x, pt.y, pt.z, fp.ms, fp.Ct, fp.clamp_hi);
-      rp[h].base = (int64_t)pt.b * fp.ms * fp.ms * fp.Ct + q.o00 + pc * 8;
+      rp[h].base = (int64_t)pt.b * fp.ms * fp.ms * fp.Ct + q.o00 + pc * M::V;
       rp[h].dx = q.o01 - q.o00; rp[h].dy = q.o10 - q.o00;        // (o11 = o00 + dx + dy: x1, y1 are clamped separately)
       rp[h].w00 = q.w00; rp[h].w01 = q.w01; rp[h].w10 = q.w10; rp[h].w11 = q.w11;
       rp[h].valid = pt.valid ? 1 : 0;
     }
   }
-  M::Raw taps[2][4];
+  typename M::Raw taps[2][4];
   auto load_taps = [&](int t) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int64_t o = rp[h].base + t * 64;
+      const int64_t o = rp[h].base + t * KT;
       taps[h][0] = M::load(fp.img_map, o);
       taps[h][1] = M::load(fp.img_map, o + rp[h].dx);
       taps[h][2] = M::load(fp.img_map, o + rp[h].dy);
@@ -76,14 +81,23 @@ __global__ __launch_bounds__(512, 2) void k_fc0_fused(FusedFc0Params fp) {
   auto produce = [&](char* astage) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      float r[8];
+      float r[M::V];
       tap_mul<M>(taps[h][0], rp[h].w00, r); tap_fma<M>(taps[h][1], rp[h].w01, r);
       tap_fma<M>(taps[h][2], rp[h].w10, r); tap_fma<M>(taps[h][3], rp[h].w11, r);
       const bool v = rp[h].valid != 0;
-      const uint2 lo = half4_inrange(v ? make_float4(r[0], r[1], r[2], r[3]) : make_float4(0.f, 0.f, 0.f, 0.f));
-      const uint2 hi = half4_inrange(v ? make_float4(r[4], r[5], r[6], r[7]) : make_float4(0.f, 0.f, 0.f, 0.f));
       const int row = pr + 64 * h;
-      *(uint4*)(astage + row * 128 + ((pc ^ fswz(row)) << 4)) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      if constexpr (F16) {
+        const uint2 lo = half4_inrange(v ? make_float4(r[0], r[1], r[2], r[3]) : make_float4(0.f, 0.f, 0.f, 0.f));
+        const uint2 hi = half4_inrange(v ? make_float4(r[4], r[5], r[6], r[7]) : make_float4(0.f, 0.f, 0.f, 0.f));
+        *(uint4*)(astage + row * 128 + ((pc ^ fswz(row)) << 4)) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      } else {
+        // store_feat4<FMT_BF16_SPLIT> (list_common.h) into the LDS row: 4 hi halfs at column 4 pc, 4 lo halfs 32 columns on
+        uint2 hi, lo;
+        split4(v ? make_float4(r[0], r[1], r[2], r[3]) : make_float4(0.f, 0.f, 0.f, 0.f), hi, lo);
+        char* base = astage + row * 128 + (pc & 1) * 8;
+        *(uint2*)(base + (((pc >> 1) ^ fswz(row)) << 4)) = hi;
+        *(uint2*)(base + (((4 + (pc >> 1)) ^ fswz(row)) << 4)) = lo;
+      }
     }
   };
 
@@ -147,18 +161,49 @@ __global__ __launch_bounds__(512, 2) void k_fc0_fused(FusedFc0Params fp) {
 
     const char* aw = smem + kFAOff + (t & 1) * kFA;
     const char* ww = smem + (t & 1) * kFW;
+    if constexpr (F16) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int coff = ((4 * ks + fo) ^ fsw) << 4;
-      bf16x8 a[4], w[8];
+      for (int ks = 0; ks < 2; ++ks) {
+        const int coff = ((4 * ks + fo) ^ fsw) << 4;
+        bf16x8 a[4], w[8];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)(aw + a_row_off + i * 16 * 128 + coff);
+        for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)(aw + a_row_off + i * 16 * 128 + coff);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) w[j] = *(const bf16x8*)(ww + w_row_off + j * 16 * 128 + coff);
+        for (int j = 0; j < 8; ++j) w[j] = *(const bf16x8*)(ww + w_row_off + j * 16 * 128 + coff);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = mfma16<1>(a[i], w[j], acc[i][j]);
+          for (int j = 0; j < 8; ++j) acc[i][j] = mfma16<1>(a[i], w[j], acc[i][j]);
+      }
+    } else {
+      // k-step 0 = the hi halfs, k-step 1 = the lo halfs of the same 32 columns; the products in k_gemm_nt_pp's order
+      const int c_hi = (fo ^ fsw) << 4, c_lo = ((4 + fo) ^ fsw) << 4;
+      bf16x8 ah[4], al[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ah[i] = *(const bf16x8*)(aw + a_row_off + i * 16 * 128 + c_hi);
+        if (X3 == 3) al[i] = *(const bf16x8*)(aw + a_row_off + i * 16 * 128 + c_lo);
+      }
+#pragma unroll
+      for (int jh = 0; jh < 2; ++jh) {
+        bf16x8 wh[4], wl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          wh[j] = *(const bf16x8*)(ww + w_row_off + (4 * jh + j) * 16 * 128 + c_hi);
+          if (X3 == 3) wl[j] = *(const bf16x8*)(ww + w_row_off + (4 * jh + j) * 16 * 128 + c_lo);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            f32x4v c = acc[i][4 * jh + j];
+            if constexpr (X3 == 3) {
+              c = mfma16<0>(al[i], wh[j], c);
+              c = mfma16<0>(ah[i], wl[j], c);
+            }
+            acc[i][4 * jh + j] = mfma16<0>(ah[i], wh[j], c);
+          }
+      }
     }
 
     if (t + 1 < np) {
@@ -203,7 +248,7 @@ __global__ __launch_bounds__(512, 2) void k_fc0_fused(FusedFc0Params fp) {
           float o[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) { o[e] = relu_nan(v[e] + bb[e]); bad = bad || (o[e] != o[e]); }
-          store8_planes<1>(p.out_hi, nullptr, (row_base + ih * 32 + r) * p.ldo + cb, o);
+          store8_planes<F16 ? 1 : 0>(p.out_hi, F16 ? nullptr : p.out_lo, (row_base + ih * 32 + r) * p.ldo + cb, o);
         }
         __syncthreads();
       }
@@ -213,12 +258,18 @@ __global__ __launch_bounds__(512, 2) void k_fc0_fused(FusedFc0Params fp) {
 }
 
 bool fused_fc0_eligible(const GemmParams& gp, int img_f16, int img_C) {
-  return gp.fmt == FMT_FP16 && gp.N == 512 && gp.M > 0 && gp.M % 128 == 0 && gp.K % 64 == 0 && img_f16 && img_C > 0 &&
-         img_C % 64 == 0 && img_C <= gp.K && gp.bias && !gp.rowvec && !gp.lda && !gp.ldw && !gp.a_rows && !gp.tile_gate;
+  if (gp.N != 512 || gp.M <= 0 || gp.M % 128 || gp.K % 64 || img_C <= 0 || img_C % 64 || img_C > gp.K || !gp.bias ||
+      gp.rowvec || gp.lda || gp.ldw || gp.a_rows || gp.tile_gate) return false;
+  // fp16 operands pair with fp16 maps; the bf16 formats (interleaved hi / lo operands) with fp32 maps
+  return gp.fmt == FMT_FP16 ? (img_f16 != 0 && !gp.x3i) : (img_f16 == 0 && gp.x3i != 0);
 }
 
-hipError_t launch_fc0_fused(const FusedFc0Params& fp, hipStream_t s) {
-  hipLaunchKernelGGL(k_fc0_fused, dim3(fp.gp.M / 128), dim3(512), 0, s, fp);
+// terms: 3 = bf16x3, 1 = plain bf16 (split formats only)
+hipError_t launch_fc0_fused(const FusedFc0Params& fp, int terms, hipStream_t s) {
+  const dim3 grid(fp.gp.M / 128);
+  if (fp.gp.fmt == FMT_FP16) hipLaunchKernelGGL(k_fc0_fused<0>, grid, dim3(512), 0, s, fp);
+  else if (terms == 3) hipLaunchKernelGGL(k_fc0_fused<3>, grid, dim3(512), 0, s, fp);
+  else hipLaunchKernelGGL(k_fc0_fused<1>, grid, dim3(512), 0, s, fp);
   return hipGetLastError();
 }
 

@@ -6,8 +6,6 @@
 //   * k_gather_tail    : scalar (C==1) voxel levels, xyz coordinates, zero padding
 // All write the bf16 hi/lo feature matrix X[row][Kp] in gather order (list_common.h).
 // Lanes run over channel quads (16-B loads, coalesced along C); a workgroup owns 64 points.
-#include <string.h>
-
 #include "list_common.h"
 #include "point_math.h"
 #include "gather_math.h"
@@ -867,55 +865,9 @@ static hipError_t launch_gather_fmt(const GatherParams& g, const FeatLayout& L, 
   // one device (tools/ab_gather.sh): with the coarse levels LAST the group takes 0.79-0.83 instead of 0.85-0.87 ms and
   // fc_0 behind it 0.50-0.53 instead of 0.48 ms -- group + fc_0 = 1.34-1.35 ms whatever the order (the X lines the
   // gathers leave dirty in the L2s drain into whatever runs next), the step 2.04-2.10 ms.  Kept: the round-2 order
-  // EXPERIMENT (round 4): LIST_FWD_FORK = 8 digits, the stream (0 = caller's, 1..3 = side streams) of
-  // [level 0 .. level 5, I, T]: the gathers of a chunk on several queues (they only run side by side that way)
-  static const char* fork_map = getenv("LIST_FWD_FORK");
-  if (fork_map && strlen(fork_map) >= LIST_N_VOX_LEVELS + 2) {
-    static hipStream_t aux[3] = {nullptr, nullptr, nullptr};
-    for (int i = 0; i < 3; ++i)
-      if (!aux[i] && (e = hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking)) != hipSuccess) return e;
-    hipEvent_t evf;
-    if ((e = hipEventCreateWithFlags(&evf, hipEventDisableTiming)) != hipSuccess) return e;
-    (void)hipEventRecord(evf, s);
-    bool used[4] = {true, false, false, false};
-    hipStream_t saved = s;
-    auto stream_of = [&](int l) { const int k = fork_map[l] - '0'; return (k >= 1 && k <= 3) ? k : 0; };
-    for (int l = 0; l < LIST_N_VOX_LEVELS + 2; ++l) {
-      const int k = stream_of(l);
-      if (k && !used[k]) { (void)hipStreamWaitEvent(aux[k - 1], evf, 0); used[k] = true; }
-    }
-    (void)hipEventDestroy(evf);
-    // launch order: LIST_GATHER_SEQ; every stream's first launch in order, the rest behind it without barriers
-    bool first[4] = {true, true, true, true};
-    bool fdone[LIST_N_VOX_LEVELS + 2] = {false};
-    for (const char* c = LIST_STR(LIST_GATHER_SEQ); ; ++c) {
-      const bool rest = *c == 0;
-      for (int l = 0; l < LIST_N_VOX_LEVELS + 2; ++l) {
-        const bool named = l < LIST_N_VOX_LEVELS ? *c == '0' + l : *c == (l == LIST_N_VOX_LEVELS ? 'I' : 'T');
-        if (fdone[l] || !(rest || named)) continue;
-        fdone[l] = true;
-        if (l < LIST_N_VOX_LEVELS && a.vox[l].C == 1) continue;
-        const int k = stream_of(l);
-        order = first[k] ? 0 : side;
-        first[k] = false;
-        s = k ? aux[k - 1] : saved;
-        if (l < LIST_N_VOX_LEVELS) e = vox_level(l);
-        else e = l == LIST_N_VOX_LEVELS ? img() : tail();
-        s = saved;
-        if (e != hipSuccess) return e;
-      }
-      if (rest) break;
-    }
-    for (int k = 1; k <= 3; ++k) {
-      if (!used[k]) continue;
-      hipEvent_t evj;
-      if ((e = hipEventCreateWithFlags(&evj, hipEventDisableTiming)) != hipSuccess) return e;
-      (void)hipEventRecord(evj, aux[k - 1]);
-      (void)hipStreamWaitEvent(saved, evj, 0);
-      (void)hipEventDestroy(evj);
-    }
-    return hipSuccess;
-  }
+  // (Round 4, measured and dropped: the seven gathers spread over two to four QUEUES -- side streams forked and joined
+  // around this group -- run side by side (group 0.85 -> 0.79 ms) but every launch around them pays for the fork / join
+  // (sort, fc_0, tail, the preps of the next step): step 2.08 -> 2.08 ... 2.18 ms over five assignments.)
   bool done[LIST_N_VOX_LEVELS + 2] = {false};
   for (const char* c = LIST_STR(LIST_GATHER_SEQ); ; ++c) {
     const bool rest = *c == 0;

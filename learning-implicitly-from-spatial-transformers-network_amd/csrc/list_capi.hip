@@ -142,22 +142,31 @@ int fused_fc0_mode() {
 #endif
     if (e[0] == '0' && e[1] == 0) return 0;
     if (e[0] == 'x') return 2;
+    if (e[0] == '3' && e[1] == 0) return 3;
     return 1;
   }();
   return mode;
 }
 bool takes_fused_fc0_any(const ListQueryArgs* a, const FeatLayout& L) {
   if (fused_fc0_mode() == 0) return false;
-  if (a->precision != LIST_PREC_FP16 || a->percep_feat || a->percep_proj || a->img_dtype != LIST_MAP_F16) return false;
+  if (a->percep_feat || a->percep_proj) return false;
+  // fp16 operands with fp16 maps, the bf16 formats with fp32 maps (the pairs the standard path takes too)
+  if ((a->precision == LIST_PREC_FP16) != (a->img_dtype == LIST_MAP_F16)) return false;
+  // bf16x3 keeps the unfused path: its packed weight is twice as long (hi + lo), and a 128-row tile streams ALL of it
+  // (7.3 MB per tile, 9.3 GB per 160 k points) -- measured (round 4): fc_0 1.15 -> 2.15 ms, step 3.58 -> 4.20 ms.
+  // LIST_FUSED_FC0=3 forces it (A/B runs, tests).
+  if (a->precision == LIST_PREC_BF16X3 && fused_fc0_mode() != 3) return false;
   // inference forwards only: list_sdf_query_bwd reads the WHOLE feature matrix (d fc_0.weight = dZ1^T . X, the perceptual
   // columns included), so a forward that a backward may follow materialises it
   if (!a->no_activations) return false;
   return a->H1 == 512 && a->img_C > 0 && a->img_C % 64 == 0 && L.img_off == 0 && L.Kp % 64 == 0;
 }
-int fused_produced_tiles(const ListQueryArgs* a) { return fused_fc0_mode() == 2 ? 0 : a->img_C / 64; }
+int fused_produced_tiles(const ListQueryArgs* a) {
+  return fused_fc0_mode() == 2 ? 0 : a->img_C / (a->precision == LIST_PREC_FP16 ? 64 : 32);
+}
 // true: the 2-D gather kernel is NOT launched (its columns are produced inside fc_0)
 bool takes_fused_fc0(const ListQueryArgs* a, const FeatLayout& L) {
-  return takes_fused_fc0_any(a, L) && fused_fc0_mode() == 1;
+  return takes_fused_fc0_any(a, L) && fused_fc0_mode() != 2;
 }
 
 // inference forwards in fp16: fc_1, fc_2 and fc_out as ONE launch (gemm_kernels.hip, k_mlp_tail_f16).  The one
@@ -495,7 +504,7 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
       fp.ms = a->map_size; fp.Ct = a->img_C; fp.clamp_hi = a->clamp_hi; fp.n_produced = fused_produced_tiles(a);
       if (!fused_fc0_eligible(gp, a->img_dtype == LIST_MAP_F16, a->img_C))
         return fail(LIST_ERR_ARG, "internal: fused fc_0 taken for arguments it does not support");
-      e = launch_fc0_fused(fp, s);
+      e = launch_fc0_fused(fp, terms, s);
     } else {
       e = launch_gemm(gp, terms, EPI_RELU_SPLIT, s);
     }
@@ -931,7 +940,7 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   if (pix && a->B > kSortImages) { sp.g.order_img = nullptr; sp.g.row_of = nullptr; bins_pix = nullptr; }
   const int map_f16 = ga->grad_img_map_dtype == LIST_MAP_F16 ? 1 : 0;
   LIST_TRY(launch_img_grad(sp, L, *a, bins_pix, nslots, bwp + bw.recs, ga->grad_img_map, map_f16, ga->grad_trans_mat,
-                           ga->stage_events, s), "image gradient launch");
+                           ga->stage_events, s, bwp + bw.img_heavy, bw.img_heavy_bytes), "image gradient launch");
   if (ga->grad_img_levels)
     LIST_TRY(launch_img_grad_to_levels(ga->grad_img_map, a->B, a->map_size, L.img_C, ga->grad_img_levels, s, map_f16,
                                        scale), "img_grad_to_levels launch");

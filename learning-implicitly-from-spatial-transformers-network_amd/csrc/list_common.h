@@ -282,11 +282,21 @@ inline PackedMlpBwd packed_mlp_bwd_layout(int Kp, int H1, int H2, int H3) {
 }
 
 // ---- backward workspace -----------------------------------------------------------------------------------
+constexpr int kSortImagesC = 64, kSortPixCellsC = 8192;      // (= kSortImages, kSortPixCells below; needed above them)
 #ifndef LIST_VOX_GATHER_MIN_DENSITY
 #define LIST_VOX_GATHER_MIN_DENSITY 2.0
 #endif
 constexpr int kColsumRows = 256;         // rows per partial of the bias-gradient column sums
 constexpr int kWgradMaxSplits = 128;
+
+// map-side gather of the perceptual-map gradient: chunks of its heavy groups (bwd_scatter_kernels.hip, kHeavyChunk =
+// 1024 candidates).  Every point is a candidate of at most 4 groups, so the chunks of groups above 1024 candidates
+// number at most 4 rows / 1024 whole ones plus one partial chunk per heavy group (<= 4 rows / 1024 of those).
+inline int img_heavy_max_chunks(int64_t rows) { return (int)(8 * rows / 1024 + 8); }
+inline size_t img_heavy_bytes(int64_t rows, int Ct) {
+  return 256 + (size_t)kSortImagesC * kSortPixCellsC * 4 + (size_t)img_heavy_max_chunks(rows) * 8 + 256 +
+         (size_t)img_heavy_max_chunks(rows) * 4 * Ct * 4;
+}
 
 struct BwdWorkspace {
   size_t scale;                              // float[4]: s, 1/s, sum(dsdf), -
@@ -297,6 +307,7 @@ struct BwdWorkspace {
   size_t colsum;                             // bias-gradient partials
   size_t recs;                               // per-point projection records (2-D gradient)
   size_t vs_keys, vs_bins, vs_sums, vs_recs; // voxel-side gather: sample keys, cell counters, scan sums, records
+  size_t img_heavy, img_heavy_bytes;         // heavy groups of the perceptual-map gradient's gather (img_heavy_bytes())
   size_t total;
 };
 inline int wgrad_nominal_splits(int M, int N) {     // enough workgroups to fill 256 CUs twice
@@ -334,6 +345,8 @@ inline BwdWorkspace bwd_workspace_layout(int64_t rows, int Kp, int H1, int H2, i
   w.vs_bins = take((size_t)4194304 * 4);
   w.vs_sums = take(1024 * 4);
   w.vs_recs = take((size_t)rows * LIST_N_STENCIL * 16);
+  w.img_heavy_bytes = img_heavy_bytes(rows, Kp);          // (the perceptual block is at most Kp columns wide)
+  w.img_heavy = take(w.img_heavy_bytes);
   w.total = o;
   return w;
 }
@@ -341,8 +354,8 @@ inline BwdWorkspace bwd_workspace_layout(int64_t rows, int Kp, int H1, int H2, i
 // ---- per-chunk workspace --------------------------------------------------------------------
 constexpr int kSortCellsPerAxis = 16;                        // Morton cells per axis per image
 constexpr int kSortCells = kSortCellsPerAxis * kSortCellsPerAxis * kSortCellsPerAxis;   // 4096
-constexpr int kSortImages = 64;                              // image slots in the key (b % 64)
-constexpr int kSortPixCells = 8192;                          // pixel-order bins per image (>= ms * ceil(ms/4))
+constexpr int kSortImages = kSortImagesC;                    // image slots in the key (b % 64)
+constexpr int kSortPixCells = kSortPixCellsC;                // pixel-order bins per image (>= ms * ceil(ms/4))
 constexpr int kSortBins = (kSortCells + kSortPixCells) * kSortImages;   // Morton + pixel counters (3 MB)
 
 constexpr int kH3 = 256;                             // fc_2's width: the C API accepts no other (list_capi.hip)
@@ -465,13 +478,14 @@ struct FusedFc0Params {
   GemmParams gp;                 // a_hi = X [M][K], w_hi = packed W0 [512][K], bias, M (% 128 == 0), N = 512, K (% 64 == 0),
                                  //   out_hi = H1, ldo, nan_tiles
   GatherParams g;                // the points behind the rows (query, order, perm, scale, N, p_begin, n_valid)
-  const void* img_map;           // prepared map [B][ms][ms][Ct] fp16
+  const void* img_map;           // prepared map [B][ms][ms][Ct]: fp16 (fp16 operands) or fp32 (bf16 formats)
   const float* trans_mat;        // [B][4][3]
   int ms, Ct; float clamp_hi;
-  int n_produced;                // leading K-tiles produced on chip (Ct / 64); 0: every K-tile from X (tile-shape diagnostic)
+  int n_produced;                // leading K-tiles produced on chip (Ct / 64, or Ct / 32 in the bf16 formats); 0: every
+                                 //   K-tile from X (tile-shape diagnostic)
 };
 bool fused_fc0_eligible(const GemmParams& gp, int img_f16, int img_C);
-hipError_t launch_fc0_fused(const FusedFc0Params& fp, hipStream_t s);
+hipError_t launch_fc0_fused(const FusedFc0Params& fp, int terms, hipStream_t s);
 // fc_1 + fc_2 + fc_out in one launch (fp16 operands, H2 = H3 = 256, nothing kept for a backward): gemm_kernels.hip
 hipError_t launch_mlp_tail(const GemmParams& fc1, const char* w2, const float* b2, const float* w3, const float* b3,
                            float* sdf, const int* order, int n_valid, hipStream_t s);
@@ -515,9 +529,12 @@ hipError_t launch_scatter_vox(const ScatterParams& sp, const FeatLayout& L, cons
                               const ListVoxLevel grad_vox[LIST_N_VOX_LEVELS], const VoxGatherBuffers& vb,
                               const ScatterStreams& st);
 // map_f16: grad_img_map receives halfs at the gradient scale (the intermediate of the adjoint resize, fp16 operands)
+// heavy / heavy_bytes: scratch of the map-side gather's heavy groups (img_heavy_bytes(); null: every group is walked by
+// its own workgroup)
 hipError_t launch_img_grad(const ScatterParams& sp, const FeatLayout& L, const ListQueryArgs& a,
                            const int* bins_pix, int nslots, void* recs, float* grad_img_map, int map_f16,
-                           float* grad_trans_mat, void* const* stage_events, hipStream_t s);
+                           float* grad_trans_mat, void* const* stage_events, hipStream_t s, void* heavy = nullptr,
+                           size_t heavy_bytes = 0);
 hipError_t launch_rows_to_grad(const ScatterParams& sp, int img_off, int C, int B, int* row_of_scratch, float* out,
                                int64_t sb, int64_t sc, int64_t sn, hipStream_t s);
 hipError_t launch_grad_to_rows(const float* src, int64_t sb, int64_t sc, int64_t sn, int B, int N, int C, float* dx,

@@ -41,11 +41,21 @@ def test_fused_fc0_equals_the_unfused_path_bit_for_bit(tmp_path):
     plain = _run(str(tmp_path), "off", "0", True)
     assert int(fused["config2_fused_fc0"]) == 1 and int(plain["config2_fused_fc0"]) == 0     # (what the library dispatched)
     assert int(fused["tiny_fused_fc0"]) == 1
+    assert int(fused["small_bf16_fused_fc0"]) == 1                     # plain bf16 too
+    assert int(fused["config2_bf16x3_fused_fc0"]) == 0                 # bf16x3 stays unfused by default (slower: W is twice as long)
     # a forward that keeps its activations for list_sdf_query_bwd materialises the whole feature matrix (d fc_0.weight
     # reads its perceptual columns): never the fused kernel
     assert int(fused["small_train_plan_fused_fc0"]) == 0
     _same(fused, plain, "fused vs unfused")
     assert np.isfinite(fused["config2_sorted"]).all() and np.abs(fused["config2_sorted"]).max() > 1e-3
+
+
+def test_fused_fc0_in_bf16x3_equals_the_unfused_path_bit_for_bit(tmp_path):
+    """LIST_FUSED_FC0=3 forces the fused kernel for the hi / lo split operands too (off by default: measured slower)."""
+    forced = _run(str(tmp_path), "x3", "3", False)
+    plain = _run(str(tmp_path), "off", "0", False)
+    assert int(forced["small_bf16x3_fused_fc0"]) == 1
+    _same(forced, plain, "fused bf16x3 vs unfused")
 
 
 def test_the_128x512_tile_alone_equals_the_256x256_kernel(tmp_path):

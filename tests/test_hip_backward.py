@@ -547,3 +547,32 @@ def test_module_forms_differentiate_through_hip(hip, golden_dir):
         a = slice_like_golden(name, k, got[k].cpu().numpy())
         assert a.shape == g[k].shape, k
         assert rel_max(a, g[k]) < TOL_X3_RELMAX, (k, rel_max(a, g[k]))
+
+
+def test_image_gradient_with_projections_piled_onto_the_clamp(hip):
+    """Thousands of points on one pixel (network/modules.py:43 clamps what leaves the map; an untrained spatial
+    transformer sends ~90 % of the points there): the map-side gather cuts such a pixel group into chunks summed by
+    separate workgroups (bwd_scatter_kernels.hip, kHeavyChunk = 1024 candidates).  Checked against (a) the atomic form of
+    the same gradient, which the unsorted forward takes (no pixel order, no groups), and (b) the oracle's autograd."""
+    seed, B, N = 7711, 2, 2600
+    c = {"query": synth.make_query(seed, B, N), "img_maps": synth.make_img_maps(seed, B, 32),
+         "vox_maps": synth.make_vox_maps(seed, B, 16), "weights": synth.make_mlp_weights(seed),
+         "trans_mat": synth.make_trans_mat(seed, B)}
+    T = c["trans_mat"].copy()
+    T[0] = np.array([[0, 0, 0], [0, 0, 0], [0, 0, 0], [-3, 500, 1]], np.float32)       # image 0: ALL points on pixel (0, 136)
+    T[1, :3, :2] *= 40.0                                                                  # image 1: most points on the borders
+    c["trans_mat"] = T
+    gs = synth.normalish(78, (B, N))
+    want = dict(want_mlp=False, want_vox=False)
+    _, piled = hip_gradients(hip, c, gs, "bf16x3", want=want)                              # pixel order: gather (+ heavy chunks)
+    _, atomic = hip_gradients(hip, c, gs, "bf16x3", sort_points=False, want=want)          # no pixel order: atomics
+    assert np.abs(atomic["img_map"]).max() > 0
+    assert rel_max(piled["img_map"], atomic["img_map"]) < 2e-5
+    assert rel_max(piled["d_trans_mat"], atomic["d_trans_mat"]) < 1e-4
+    # all of image 0's gradient mass sits on the two map rows / columns its one pixel touches
+    g0 = np.abs(piled["img_map"][0]).sum(-1)
+    assert g0[136, 0] > 0 and g0[:135].sum() == 0 and g0[:, 2:].sum() == 0
+    args = TO.to_torch(c)
+    _, ref = TO.list_query_grads(*args, torch.from_numpy(gs))
+    for i in range(5):
+        assert rel_max(piled[f"d_img{i}"], ref[f"d_img{i}"].numpy()) < 5e-2, i            # (masks may flip: not margin-seeded)

@@ -31,6 +31,8 @@ def kernel_key(name, grid, seq):
     k, t = m.group(1), (m.group(2) or "")
     if k == "k_mlp_tail_f16":                 # fc_1 + fc_2 + fc_out in one launch (fp16 inference forwards)
         return "fc_2_out"
+    if k == "k_fc0_fused":                    # fc_0 with the perceptual block produced on chip (fp16 inference forwards)
+        return "fc_0"
     if k == "k_gemm_nt_pp":                   # ping-pong schedule: fc_0 (1250 tiles) and, in fp16, fc_1 (625 tiles)
         return "fc_0" if grid >= 600000 else "fc_1"
     if k in ("k_gemm_nt", "k_gemm_nt16"):
