@@ -206,6 +206,13 @@ typedef struct ListQueryArgs {
                                         /*   (default): H1, H2, H3 are left in the workspace for the */
                                         /*   backward.  list_sdf_query_bwd refuses (LIST_ERR_ARG) a  */
                                         /*   forward that had it set.                                */
+  int32_t no_fused_fc0;                 /* ABI 7.  0 (default): an inference forward (no_activations) with  */
+                                        /*   fp16 or plain-bf16 operands runs fc_0 as k_fc0_fused -- the     */
+                                        /*   perceptual block of its A operand (modules.py:46-53) is sampled */
+                                        /*   into LDS inside the kernel, no 2-D gather kernel is launched    */
+                                        /*   and those columns of the feature matrix never reach HBM.  1:    */
+                                        /*   the unfused pair (k_gather_img + k_gemm_nt_pp).  Same bits      */
+                                        /*   either way (tests/test_fused_fc0_gpu.py).                       */
 } ListQueryArgs;
 
 /* Boundaries recorded into ListQueryArgs.stage_events: one hipEvent after each kernel (group) of a

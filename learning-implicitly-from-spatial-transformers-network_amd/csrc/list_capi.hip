@@ -158,7 +158,7 @@ bool takes_fused_fc0_any(const ListQueryArgs* a, const FeatLayout& L) {
   if (a->precision == LIST_PREC_BF16X3 && fused_fc0_mode() != 3) return false;
   // inference forwards only: list_sdf_query_bwd reads the WHOLE feature matrix (d fc_0.weight = dZ1^T . X, the perceptual
   // columns included), so a forward that a backward may follow materialises it
-  if (!a->no_activations) return false;
+  if (!a->no_activations || a->no_fused_fc0) return false;
   return a->H1 == 512 && a->img_C > 0 && a->img_C % 64 == 0 && L.img_off == 0 && L.Kp % 64 == 0;
 }
 int fused_produced_tiles(const ListQueryArgs* a) {
@@ -418,6 +418,9 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
       a->precision != LIST_PREC_FP16)
     return fail(LIST_ERR_ARG, "precision=%d", a->precision);
   // (a flag, not a count: anything else is a struct of another ABI version or an uninitialised one)
+  if (a->no_fused_fc0 != 0 && a->no_fused_fc0 != 1)
+    return fail(LIST_ERR_ARG, "no_fused_fc0=%d (0 or 1; zero-initialise ListQueryArgs, list_abi_version() = %d)",
+                a->no_fused_fc0, LIST_ABI_VERSION);
   if (a->no_activations != 0 && a->no_activations != 1)
     return fail(LIST_ERR_ARG, "no_activations=%d (0 or 1; zero-initialise ListQueryArgs, list_abi_version() = %d)",
                 a->no_activations, LIST_ABI_VERSION);

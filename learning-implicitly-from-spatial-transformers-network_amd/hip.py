@@ -71,7 +71,8 @@ class ListQueryArgs(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("precision", C.c_int32),
                 ("stage_events", C.POINTER(C.c_void_p)), ("no_sort", C.c_int32),
-                ("stage_event_sets", C.c_int32), ("percep_proj", C.c_void_p), ("no_activations", C.c_int32)]
+                ("stage_event_sets", C.c_int32), ("percep_proj", C.c_void_p), ("no_activations", C.c_int32),
+                ("no_fused_fc0", C.c_int32)]
 
 
 class ListMlpGrads(C.Structure):
@@ -493,7 +494,7 @@ class QueryContext:
 
 def sdf_query(query, trans_mat, img, vox, packed, perm=(2, 1, 0), scale=2.0, precision="bf16x3",
               percep_feat=None, out=None, stage_events=None, sort_points=True, clamp_hi=136.0,
-              save_for_backward=False, percep_proj=None, plan=None):
+              save_for_backward=False, percep_proj=None, plan=None, fused_fc0=True):
     """The fused hot path, network/models.py:91-97 -> sdf [B,N] (float32).
 
     plan: optional dict, filled with what the library dispatches for this call (list_query_plan: chunks,
@@ -512,6 +513,7 @@ def sdf_query(query, trans_mat, img, vox, packed, perm=(2, 1, 0), scale=2.0, pre
     a.no_sort = 0 if sort_points else 1
     # nothing is kept for a backward: fc_1 / fc_2 / fc_out run as one kernel (fp16 operands), H2 stays in registers
     a.no_activations = int(keeps_no_activations(save_for_backward))
+    a.no_fused_fc0 = 0 if fused_fc0 else 1            # (A/B runs: the 2-D gather kernel + k_gemm_nt_pp instead of k_fc0_fused)
     if percep_proj is not None:
         if save_for_backward or percep_feat is not None:
             raise RuntimeError("percep_proj is an inference path: no backward, no pre-pooled features")

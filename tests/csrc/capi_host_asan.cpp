@@ -104,6 +104,8 @@ int main() {
   EXPECT(list_sdf_query_fwd(&e, NULL) == LIST_ERR_ARG);
   e = a; e.no_activations = 2;
   EXPECT(list_sdf_query_fwd(&e, NULL) == LIST_ERR_ARG);
+  e = a; e.no_fused_fc0 = -3;
+  EXPECT(list_sdf_query_fwd(&e, NULL) == LIST_ERR_ARG);
   e = a; e.workspace = (char*)e.workspace + 8;
   EXPECT(list_sdf_query_fwd(&e, NULL) == LIST_ERR_SHAPE);
   e = a; e.workspace_bytes = 1 << 20;
@@ -121,8 +123,11 @@ int main() {
   EXPECT(list_query_plan(NULL, &pl) == LIST_ERR_ARG);
   EXPECT(list_query_plan(&a, &pl) == LIST_OK && pl.chunks == 1 && pl.rows_per_chunk == 160000 && pl.fused_tail == 1 &&
          pl.fc0_k == 3648 && pl.box_levels == ((1 << 4) | (1 << 5)));
+  EXPECT(pl.fused_fc0 == 1);                                                  // inference forward, fp16 operands and maps
+  e = a; e.no_fused_fc0 = 1;
+  EXPECT(list_query_plan(&e, &pl) == LIST_OK && pl.fused_fc0 == 0 && pl.fused_tail == 1);
   e = a; e.no_activations = 0;
-  EXPECT(list_query_plan(&e, &pl) == LIST_OK && pl.fused_tail == 0);
+  EXPECT(list_query_plan(&e, &pl) == LIST_OK && pl.fused_tail == 0 && pl.fused_fc0 == 0);
   e = a; e.precision = LIST_PREC_BF16X3;
   EXPECT(list_query_plan(&e, &pl) == LIST_OK && pl.fused_tail == 0 && pl.box_levels == 0);
   ListQueryArgs g = good_query(1, 256 * 256 * 256, fake(0x40000000), ws_grid);
