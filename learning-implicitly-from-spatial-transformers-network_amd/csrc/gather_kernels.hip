@@ -6,6 +6,8 @@
 //   * k_gather_tail    : scalar (C==1) voxel levels, xyz coordinates, zero padding
 // All write the bf16 hi/lo feature matrix X[row][Kp] in gather order (list_common.h).
 // Lanes run over channel quads (16-B loads, coalesced along C); a workgroup owns 64 points.
+#include <string.h>
+
 #include "list_common.h"
 #include "point_math.h"
 #include "gather_math.h"
@@ -82,12 +84,23 @@ __device__ __forceinline__ void reduce_taps(const typename M::Raw (&v)[8], const
   for (int k = 1; k < 8; ++k) tap_fma<M>(v[k], t.w[k], acc);
 }
 
+// The scalar level that shares this level's grid (C == 1, same D x H x W: the occupancy level next to the 128^3 x 16
+// one) rides along (round 4): its 8 taps sit at the same voxel indices with the same weights, so the lane with sub == 0
+// takes stencil point J0's sample of it and the lane with sub == 1 J1's -- 8 scalar loads beside the 16-B tap loads of
+// the pair -- and k_gather_tail (56 dependent scalar taps per point in a launch of its own, 0.059 ms) is not launched.
+// Same arithmetic as k_gather_tail (reduce_taps1, its NaN re-reduction, the 16-bit store of put<>): the same bits.
+struct TailRide {
+  const float* l0;            // image base of the scalar level (fp32, [D][H][W])
+  int64_t out;                // X offset of its 7 columns in this row
+  int sub, lp;                // this lane's index among the point's lanes, lanes per point
+};
+
 // Two stencil points at a time: all 16 tap loads are issued before the first use, so a wave has
 // 16 KB in flight per step instead of one dependent 8-load round trip per stencil point.
-template <int C, int J0, int J1, int FMT, typename M>
+template <int C, int J0, int J1, int FMT, typename M, int TAIL = 0>
 __device__ __forceinline__ void gather_pair(const ListVoxLevel& lv, const void* __restrict__ base,
                                             int64_t boff, const Pt& p, unsigned short* __restrict__ xh,
-                                            unsigned short* __restrict__ xl, int64_t out_off) {
+                                            unsigned short* __restrict__ xl, int64_t out_off, const TailRide& tr) {
   float x0, y0, z0, x1, y1, z1;
   stencil_point<J0>(p, x0, y0, z0);
   stencil_point<J1>(p, x1, y1, z1);
@@ -100,12 +113,56 @@ __device__ __forceinline__ void gather_pair(const ListVoxLevel& lv, const void* 
 #pragma unroll
     for (int k = 0; k < 8; ++k) v1[k] = M::load(base, boff + t1.o[k]);
   }
+  // the scalar level's sample of this lane: J0 (sub == 0) or J1 (the next lane; the same lane when a point has one)
+  const int second = tr.lp > 1 ? 1 : 0;
+  const bool take0 = TAIL && tr.sub == 0, take1 = TAIL && J1 != J0 && tr.sub == second;
+  float sv[8], sw[8];
+  int sdead = 0;
+  if (TAIL && (take0 || take1) && !(take0 && take1)) {
+    constexpr int SH = C == 4 ? 2 : C == 8 ? 3 : C == 16 ? 4 : C == 32 ? 5 : C == 64 ? 6 : C == 128 ? 7 : 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      sv[k] = tr.l0[(take0 ? t0.o[k] : t1.o[k]) >> SH];
+      sw[k] = take0 ? t0.w[k] : t1.w[k];
+    }
+    sdead = take0 ? t0.dead : t1.dead;
+  }
   float r[M::V];
   reduce_taps<M>(v0, t0, r);
   store_feats<FMT, M::V>(xh, xl, out_off + J0 * C, r, p.valid);
   if (J1 != J0) {
     reduce_taps<M>(v1, t1, r);
     store_feats<FMT, M::V>(xh, xl, out_off + J1 * C, r, p.valid);
+  }
+  if (TAIL && (take0 || take1) && !(take0 && take1)) {
+    float a = sv[0] * sw[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) a = fmaf(sv[k], sw[k], a);
+    if (a != a) {                             // (k_gather_tail: skipped taps re-reduced with their values forced to zero)
+      a = sv[0] * sw[0];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) a = fmaf(((sdead >> k) & 1) ? 0.f : sv[k], sw[k], a);
+    }
+    store_feat1<FMT>(xh, xl, tr.out + (take0 ? J0 : J1), p.valid ? a : 0.f);
+  }
+  if (TAIL && take0 && take1) {               // one lane per point (C == V): both samples, one after the other
+    constexpr int SH = C == 4 ? 2 : C == 8 ? 3 : 4;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      const Taps& t = which ? t1 : t0;
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = tr.l0[t.o[k] >> SH];
+      float a = v[0] * t.w[0];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) a = fmaf(v[k], t.w[k], a);
+      if (a != a) {
+        a = v[0] * t.w[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) a = fmaf(((t.dead >> k) & 1) ? 0.f : v[k], t.w[k], a);
+      }
+      store_feat1<FMT>(xh, xl, tr.out + (which ? J1 : J0), p.valid ? a : 0.f);
+    }
   }
 }
 
@@ -122,8 +179,14 @@ template <int C, int V> struct VoxGeom {
 #ifndef LIST_VOX_WAVES
 #define LIST_VOX_WAVES 1
 #endif
-template <int C, int FMT, int F16>
-__global__ __launch_bounds__(256, LIST_VOX_WAVES) void k_gather_vox(GatherParams g, ListVoxLevel lv, int col_off) {
+// TAIL: the scalar level of the same grid, xyz and the zero padding ride along (TailRide above; k_gather_tail's work)
+struct TailArgs { const float* l0; int64_t l0_stride; int l0_off, xyz_off, F; int* nan_tiles; };
+
+template <int FMT>
+__device__ __forceinline__ void write_xyz_and_pad(const GatherParams& g, const Pt& p, int64_t ro, int xyz_off, int F);
+
+template <int C, int FMT, int F16, int TAIL = 0>
+__global__ __launch_bounds__(256, LIST_VOX_WAVES) void k_gather_vox(GatherParams g, ListVoxLevel lv, int col_off, TailArgs ta) {
   using M = MapT<F16>;
   using G = VoxGeom<C, M::V>;
   __shared__ Pt pts[G::RB];
@@ -131,6 +194,8 @@ __global__ __launch_bounds__(256, LIST_VOX_WAVES) void k_gather_vox(GatherParams
   const int sub = lane % G::LP, psub = lane / G::LP;
   const int blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
   if (threadIdx.x < G::RB) pts[threadIdx.x] = load_point(g, blk * G::RB + threadIdx.x);
+  if (TAIL && ta.nan_tiles && threadIdx.x == 0 && ((blk * G::RB) % kRowTile) == 0)
+    ta.nan_tiles[(blk * G::RB) / kRowTile] = 0;                    // cleared for fc_0's probe (k_gather_tail's job otherwise)
   __syncthreads();
   unsigned short* __restrict__ xh = g.x_hi;
   unsigned short* __restrict__ xl = g.x_lo;
@@ -141,10 +206,14 @@ __global__ __launch_bounds__(256, LIST_VOX_WAVES) void k_gather_vox(GatherParams
     const Pt p = pts[local];
     const int64_t boff = (int64_t)p.b * lv.image_stride + sub * M::V;
     const int64_t out_off = (int64_t)row * g.Kp + col_off + sub * M::V;
-    gather_pair<C, 0, 1, FMT, M>(lv, lv.data, boff, p, xh, xl, out_off);
-    gather_pair<C, 2, 3, FMT, M>(lv, lv.data, boff, p, xh, xl, out_off);
-    gather_pair<C, 4, 5, FMT, M>(lv, lv.data, boff, p, xh, xl, out_off);
-    gather_pair<C, 6, 6, FMT, M>(lv, lv.data, boff, p, xh, xl, out_off);
+    TailRide tr;
+    tr.l0 = TAIL ? ta.l0 + (int64_t)p.b * ta.l0_stride : nullptr;
+    tr.out = (int64_t)row * g.Kp + ta.l0_off; tr.sub = sub; tr.lp = G::LP;
+    gather_pair<C, 0, 1, FMT, M, TAIL>(lv, lv.data, boff, p, xh, xl, out_off, tr);
+    gather_pair<C, 2, 3, FMT, M, TAIL>(lv, lv.data, boff, p, xh, xl, out_off, tr);
+    gather_pair<C, 4, 5, FMT, M, TAIL>(lv, lv.data, boff, p, xh, xl, out_off, tr);
+    gather_pair<C, 6, 6, FMT, M, TAIL>(lv, lv.data, boff, p, xh, xl, out_off, tr);
+    if (TAIL && sub == (G::LP > 1 ? 1 : 0)) write_xyz_and_pad<FMT>(g, p, (int64_t)row * g.Kp, ta.xyz_off, ta.F);
   }
 }
 
@@ -651,6 +720,11 @@ __global__ __launch_bounds__(256) void k_gather_tail(GatherParams g, TailLevels 
     }
     return;
   }
+  write_xyz_and_pad<FMT>(g, p, ro, xyz_off, F);
+}
+
+template <int FMT>
+__device__ __forceinline__ void write_xyz_and_pad(const GatherParams& g, const Pt& p, int64_t ro, int xyz_off, int F) {
   put<FMT>(g, ro + xyz_off + 0, p.valid ? p.x : 0.f);     // p_features, modules.py:257
   put<FMT>(g, ro + xyz_off + 1, p.valid ? p.y : 0.f);
   put<FMT>(g, ro + xyz_off + 2, p.valid ? p.z : 0.f);
@@ -760,28 +834,38 @@ hipError_t launch_gather_fixup(const GatherParams& g, const FeatLayout& L, const
 // barrier (list_common.h, LIST_LAUNCH / any_order()): six drains of the chip less per chunk, 0.91 -> 0.86 ms for the
 // seven launches of the metric's shape.  `order` = 0 keeps the plain in-order launch (taken for all seven when the
 // caller asks for a stage event between two gathers: per-kernel timing).
+static bool vox_level_is_near(const ListVoxLevel& lv) {
+  const int big = lv.W > lv.H ? (lv.W > lv.D ? lv.W : lv.D) : (lv.H > lv.D ? lv.H : lv.D);
+  return kDisp * 0.5f * (float)(big - 1) < 0.99f && lv.C >= 16;           // stencil stays within one cell
+}
+
+// ride: the scalar level / xyz / padding that this level's kernel writes too (k_gather_vox only), or null
 template <int C, int FMT, int F16>
 static hipError_t launch_vox_level_t(const GatherParams& g, const ListVoxLevel& lv, int col_off,
-                                     hipStream_t s, int order) {
+                                     hipStream_t s, int order, const TailArgs* ride) {
   using G = VoxGeom<C, MapT<F16>::V>;
-  const int big = lv.W > lv.H ? (lv.W > lv.D ? lv.W : lv.D) : (lv.H > lv.D ? lv.H : lv.D);
-  const bool near = kDisp * 0.5f * (float)(big - 1) < 0.99f && C >= 16;   // stencil stays within one cell
+  const bool near = vox_level_is_near(lv);
   if (near && gather_box_eligible(g, lv, col_off)) return launch_gather_vox_box(g, lv, col_off, s, order);
+  TailArgs none;
+  memset(&none, 0, sizeof(none));
   if (near)
     LIST_LAUNCH((k_gather_vox_near<C, FMT, F16>), dim3(g.rows / G::RB), dim3(256), 0, s, order, g, lv, col_off);
-  else
-    LIST_LAUNCH((k_gather_vox<C, FMT, F16>), dim3(g.rows / G::RB), dim3(256), 0, s, order, g, lv, col_off);
+  else if (ride) {
+    if constexpr (C <= 64) LIST_LAUNCH((k_gather_vox<C, FMT, F16, 1>), dim3(g.rows / G::RB), dim3(256), 0, s, order, g, lv, col_off, *ride);
+    else return hipErrorInvalidValue;
+  } else
+    LIST_LAUNCH((k_gather_vox<C, FMT, F16, 0>), dim3(g.rows / G::RB), dim3(256), 0, s, order, g, lv, col_off, none);
   return hipGetLastError();
 }
 
 template <int C, int FMT>
 static hipError_t launch_vox_level(const GatherParams& g, const ListVoxLevel& lv, int col_off,
-                                   hipStream_t s, int order) {
+                                   hipStream_t s, int order, const TailArgs* ride) {
   if (lv.dtype == LIST_MAP_F16) {
-    if constexpr (C >= 8) return launch_vox_level_t<C, FMT, 1>(g, lv, col_off, s, order);
+    if constexpr (C >= 8) return launch_vox_level_t<C, FMT, 1>(g, lv, col_off, s, order, ride);
     else return hipErrorInvalidValue;
   }
-  return launch_vox_level_t<C, FMT, 0>(g, lv, col_off, s, order);
+  return launch_vox_level_t<C, FMT, 0>(g, lv, col_off, s, order, ride);
 }
 
 #ifndef LIST_GATHER_SEQ
@@ -806,16 +890,36 @@ static hipError_t launch_gather_fmt(const GatherParams& g, const FeatLayout& L, 
   for (int l = 0; l < LIST_N_VOX_LEVELS; ++l)
     if (a.vox[l].C == 1) { tl.lv[tl.n] = a.vox[l]; tl.off[tl.n] = L.vox_off[l]; ++tl.n; }
 
+  // The scalar level rides along with the vector level of the same grid (gather_pair, TailRide): one scalar level,
+  // fp32 in place, and a level of 8 .. 64 channels with its dimensions that takes k_gather_vox.  LIST_TAIL_RIDE=0 keeps
+  // k_gather_tail (A/B runs).
+  static const bool ride_on = [] { const char* e = getenv("LIST_TAIL_RIDE"); return !(e && e[0] == '0' && e[1] == 0); }();
+  int ride_level = -1;
+  TailArgs ride;
+  memset(&ride, 0, sizeof(ride));
+  if (ride_on && tl.n == 1 && tl.lv[0].dtype == LIST_MAP_F32) {
+    for (int l = 0; l < LIST_N_VOX_LEVELS && ride_level < 0; ++l) {
+      const ListVoxLevel& lv = a.vox[l];
+      if (lv.C >= 8 && lv.C <= 64 && lv.D == tl.lv[0].D && lv.H == tl.lv[0].H && lv.W == tl.lv[0].W && !vox_level_is_near(lv) &&
+          (int64_t)lv.D * lv.H * lv.W * lv.C < ((int64_t)1 << 31))
+        ride_level = l;
+    }
+    if (ride_level >= 0) {
+      ride.l0 = (const float*)tl.lv[0].data; ride.l0_stride = tl.lv[0].image_stride; ride.l0_off = tl.off[0];
+      ride.xyz_off = L.xyz_off; ride.F = L.F; ride.nan_tiles = nan_tiles;
+    }
+  }
   auto vox_level = [&](int l) -> hipError_t {
     const ListVoxLevel& lv = a.vox[l];
+    const TailArgs* rd = l == ride_level ? &ride : nullptr;
     switch (lv.C) {
-      case 4: return launch_vox_level<4, FMT>(g, lv, L.vox_off[l], s, order);
-      case 8: return launch_vox_level<8, FMT>(g, lv, L.vox_off[l], s, order);
-      case 16: return launch_vox_level<16, FMT>(g, lv, L.vox_off[l], s, order);
-      case 32: return launch_vox_level<32, FMT>(g, lv, L.vox_off[l], s, order);
-      case 64: return launch_vox_level<64, FMT>(g, lv, L.vox_off[l], s, order);
-      case 128: return launch_vox_level<128, FMT>(g, lv, L.vox_off[l], s, order);
-      case 256: return launch_vox_level<256, FMT>(g, lv, L.vox_off[l], s, order);
+      case 4: return launch_vox_level<4, FMT>(g, lv, L.vox_off[l], s, order, rd);
+      case 8: return launch_vox_level<8, FMT>(g, lv, L.vox_off[l], s, order, rd);
+      case 16: return launch_vox_level<16, FMT>(g, lv, L.vox_off[l], s, order, rd);
+      case 32: return launch_vox_level<32, FMT>(g, lv, L.vox_off[l], s, order, rd);
+      case 64: return launch_vox_level<64, FMT>(g, lv, L.vox_off[l], s, order, rd);
+      case 128: return launch_vox_level<128, FMT>(g, lv, L.vox_off[l], s, order, rd);
+      case 256: return launch_vox_level<256, FMT>(g, lv, L.vox_off[l], s, order, rd);
       default: return hipErrorInvalidValue;
     }
   };
@@ -841,6 +945,7 @@ static hipError_t launch_gather_fmt(const GatherParams& g, const FeatLayout& L, 
     return hipGetLastError();
   };
   auto tail = [&]() -> hipError_t {
+    if (ride_level >= 0) return hipSuccess;           // written by the riding level's kernel
     LIST_LAUNCH(k_gather_tail<FMT>, dim3((g.rows + 31) / 32), dim3(256), 0, s, order, g, tl, L.xyz_off, L.F, nan_tiles);
     return hipGetLastError();
   };

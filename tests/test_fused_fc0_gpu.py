@@ -14,12 +14,14 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run(tmp_path, tag, mode, full):
+def _run(tmp_path, tag, mode, full, extra_env=None):
     out = os.path.join(tmp_path, f"fused_{tag}.npz")
     env = dict(os.environ)
     env.pop("LIST_FUSED_FC0", None)
+    env.pop("LIST_TAIL_RIDE", None)
     if mode is not None:
         env["LIST_FUSED_FC0"] = mode
+    env.update(extra_env or {})
     r = subprocess.run([sys.executable, os.path.join(HERE, "_child_fused_fc0.py"), out] + (["full"] if full else []),
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -64,3 +66,12 @@ def test_the_128x512_tile_alone_equals_the_256x256_kernel(tmp_path):
     tile = _run(str(tmp_path), "x", "x", False)
     plain = _run(str(tmp_path), "off", "0", False)
     _same(tile, plain, "128x512 tile vs 256x256")
+
+
+def test_scalar_level_riding_with_the_fine_level_equals_the_tail_kernel(tmp_path):
+    """The C = 1 occupancy level, xyz and the zero padding written by the 128^3 x 16 level's gather kernel (gather_pair,
+    TailRide) against k_gather_tail (LIST_TAIL_RIDE=0): the same arithmetic, the same bits -- every golden case, the
+    non-finite ones and their exact redo included, fp16 / bf16x3 / bf16, sorted and unsorted, and a training forward."""
+    ride = _run(str(tmp_path), "ride", None, False)
+    tail = _run(str(tmp_path), "tail", None, False, {"LIST_TAIL_RIDE": "0"})
+    _same(ride, tail, "riding scalar level vs k_gather_tail")
