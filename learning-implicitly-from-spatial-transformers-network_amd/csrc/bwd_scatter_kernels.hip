@@ -1249,7 +1249,7 @@ __global__ __launch_bounds__(256) void k_trans_grad(ScatterParams sp, const void
 hipError_t launch_img_grad(const ScatterParams& sp, const FeatLayout& L, const ListQueryArgs& a,
                            const int* bins_pix, int nslots, void* recs, float* grad_img_map, int map_f16,
                            float* grad_trans_mat, void* const* stage_events, hipStream_t s, void* heavy,
-                           size_t heavy_bytes) {
+                           size_t heavy_bytes, hipStream_t s_trans) {
   (void)nslots;
   const int ms = a.map_size, Ct = L.img_C;
   ImgRec* rc = (ImgRec*)recs;
@@ -1315,22 +1315,26 @@ hipError_t launch_img_grad(const ScatterParams& sp, const FeatLayout& L, const L
   }
   mark(LIST_BWD_IMG);
   if (grad_trans_mat) {
+    // The gradient of trans_mat reads dX and the map, nothing of the map gradient above: forked, it goes to the stream of the
+    // direct-atomic voxel levels, which has run dry by now, instead of standing between the map-side gather and the adjoint
+    // resize on the caller's stream (round 4; that stream is behind dX already)
+    hipStream_t st = s_trans ? s_trans : s;
     const int B = (int)((sp.g.p_begin + sp.g.n_valid + sp.g.N - 1) / sp.g.N);
-    hipError_t e = hipMemsetAsync(grad_trans_mat, 0, (size_t)B * 12 * sizeof(float), s);
+    hipError_t e = hipMemsetAsync(grad_trans_mat, 0, (size_t)B * 12 * sizeof(float), st);
     if (e != hipSuccess) return e;
     const dim3 grid((unsigned)(sp.g.rows / kGatherRows));
     const int f16 = a.img_dtype == LIST_MAP_F16;
     if (f16 && sp.dx_f16)
-      hipLaunchKernelGGL((k_trans_grad<1, 1>), grid, dim3(256), 0, s, sp, a.img_map, a.trans_mat, ms, Ct, a.clamp_hi,
+      hipLaunchKernelGGL((k_trans_grad<1, 1>), grid, dim3(256), 0, st, sp, a.img_map, a.trans_mat, ms, Ct, a.clamp_hi,
                          L.img_off, grad_trans_mat);
     else if (f16)
-      hipLaunchKernelGGL((k_trans_grad<1, 0>), grid, dim3(256), 0, s, sp, a.img_map, a.trans_mat, ms, Ct, a.clamp_hi,
+      hipLaunchKernelGGL((k_trans_grad<1, 0>), grid, dim3(256), 0, st, sp, a.img_map, a.trans_mat, ms, Ct, a.clamp_hi,
                          L.img_off, grad_trans_mat);
     else if (sp.dx_f16)
-      hipLaunchKernelGGL((k_trans_grad<0, 1>), grid, dim3(256), 0, s, sp, a.img_map, a.trans_mat, ms, Ct, a.clamp_hi,
+      hipLaunchKernelGGL((k_trans_grad<0, 1>), grid, dim3(256), 0, st, sp, a.img_map, a.trans_mat, ms, Ct, a.clamp_hi,
                          L.img_off, grad_trans_mat);
     else
-      hipLaunchKernelGGL((k_trans_grad<0, 0>), grid, dim3(256), 0, s, sp, a.img_map, a.trans_mat, ms, Ct, a.clamp_hi,
+      hipLaunchKernelGGL((k_trans_grad<0, 0>), grid, dim3(256), 0, st, sp, a.img_map, a.trans_mat, ms, Ct, a.clamp_hi,
                          L.img_off, grad_trans_mat);
     e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -943,7 +943,13 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   if (pix && a->B > kSortImages) { sp.g.order_img = nullptr; sp.g.row_of = nullptr; bins_pix = nullptr; }
   const int map_f16 = ga->grad_img_map_dtype == LIST_MAP_F16 ? 1 : 0;
   LIST_TRY(launch_img_grad(sp, L, *a, bins_pix, nslots, bwp + bw.recs, ga->grad_img_map, map_f16, ga->grad_trans_mat,
-                           ga->stage_events, s, bwp + bw.img_heavy, bw.img_heavy_bytes), "image gradient launch");
+                           ga->stage_events, s, bwp + bw.img_heavy, bw.img_heavy_bytes,
+#ifdef LIST_BWD_TRANS_INLINE      /* A/B: the trans_mat gradient stays on the caller's stream */
+                           s
+#else
+                           forked ? s_direct : s
+#endif
+                           ), "image gradient launch");
   if (ga->grad_img_levels)
     LIST_TRY(launch_img_grad_to_levels(ga->grad_img_map, a->B, a->map_size, L.img_C, ga->grad_img_levels, s, map_f16,
                                        scale), "img_grad_to_levels launch");

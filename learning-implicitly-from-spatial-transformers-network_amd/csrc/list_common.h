@@ -534,7 +534,7 @@ hipError_t launch_scatter_vox(const ScatterParams& sp, const FeatLayout& L, cons
 hipError_t launch_img_grad(const ScatterParams& sp, const FeatLayout& L, const ListQueryArgs& a,
                            const int* bins_pix, int nslots, void* recs, float* grad_img_map, int map_f16,
                            float* grad_trans_mat, void* const* stage_events, hipStream_t s, void* heavy = nullptr,
-                           size_t heavy_bytes = 0);
+                           size_t heavy_bytes = 0, hipStream_t s_trans = nullptr);
 hipError_t launch_rows_to_grad(const ScatterParams& sp, int img_off, int C, int B, int* row_of_scratch, float* out,
                                int64_t sb, int64_t sc, int64_t sn, hipStream_t s);
 hipError_t launch_grad_to_rows(const float* src, int64_t sb, int64_t sc, int64_t sn, int B, int N, int C, float* dx,
