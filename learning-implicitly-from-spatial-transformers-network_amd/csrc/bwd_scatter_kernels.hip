@@ -1315,9 +1315,7 @@ hipError_t launch_img_grad(const ScatterParams& sp, const FeatLayout& L, const L
   }
   mark(LIST_BWD_IMG);
   if (grad_trans_mat) {
-    // The gradient of trans_mat reads dX and the map, nothing of the map gradient above: forked, it goes to the stream of the
-    // direct-atomic voxel levels, which has run dry by now, instead of standing between the map-side gather and the adjoint
-    // resize on the caller's stream (round 4; that stream is behind dX already)
+    // (s_trans: list_capi.hip may place this stage on the direct-atomic levels' stream -- opt-in, see there)
     hipStream_t st = s_trans ? s_trans : s;
     const int B = (int)((sp.g.p_begin + sp.g.n_valid + sp.g.N - 1) / sp.g.N);
     hipError_t e = hipMemsetAsync(grad_trans_mat, 0, (size_t)B * 12 * sizeof(float), st);
