@@ -44,6 +44,11 @@ bool vox_in_place(const ListMap3D& m, ListVoxLevel* lv, int32_t map_dtype) {
     if (m.sw == 1 && m.sh == W && m.sd == H * W) { lv->data = m.data; lv->image_stride = m.sb; return true; }
     return false;
   }
+  // fp16 maps asked for and the level is one the matrix-core gather takes (128 channels, at most 31 voxels a side:
+  // k_gather_vox_box wants fp16 voxels): a channels-last fp32 level is then CONVERTED (1 - 8 MB per batch, a few
+  // microseconds) rather than used in place -- in place it fell back to the scalar shared-tap kernel on 4-byte taps
+  // (round 4, the module path on channels-last encoders: levels 4 + 5 0.27 -> 0.20 ms)
+  if (map_dtype == LIST_MAP_F16 && m.C == 128 && m.D <= 31 && m.H <= 31 && m.W <= 31) return false;
   if (m.sc == 1 && m.sw == C && m.sh == W * C && m.sd == H * W * C && aligned16(m.data) &&
       (m.sb % 4) == 0) {
     lv->data = m.data; lv->image_stride = m.sb; return true;
@@ -268,6 +273,15 @@ int list_prep_vox_maps(const ListMap3D maps[LIST_N_VOX_LEVELS], int32_t B, int32
     if (vox_in_place(m, &levels_out[l], map_dtype)) continue;
     const bool f16 = level_as_f16(m, map_dtype);
     void* dst = (char*)pack + off;
+    // a dense channels-last fp32 level that only changes its element type (the matrix-core gather's levels, see
+    // vox_in_place): one elementwise pass, no transposition
+    const int64_t vol = (int64_t)m.D * m.H * m.W;
+    if (f16 && m.dtype == LIST_MAP_F32 && m.sc == 1 && m.sw == m.C && m.sh == (int64_t)m.W * m.C &&
+        m.sd == (int64_t)m.H * m.W * m.C && m.sb == vol * m.C && aligned16(m.data) && ((vol * m.C * B) % 4) == 0) {
+      hipError_t e = launch_split((const float*)m.data, (unsigned short*)dst, nullptr, vol * m.C * B, FMT_FP16,
+                                  (hipStream_t)stream);
+      if (e != hipSuccess) return hip_fail(e, "fp16 conversion launch");
+    } else
 #ifndef LIST_TRANSPOSE_NO_FUSE
     if (transpose_tile_eligible(m, dst)) {           // launched together below
       fused_maps[n_fused] = m; fused_out[n_fused] = dst; fused_f16[n_fused] = f16 ? 1 : 0; ++n_fused;
