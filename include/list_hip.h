@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LIST_ABI_VERSION 7
+#define LIST_ABI_VERSION 8
 
 #define LIST_N_IMG_LEVELS 5   /* ResEncoder feature maps, network/modules.py:1067 */
 #define LIST_N_VOX_LEVELS 6   /* VoxelEncoder2 feature maps, network/modules.py:425-442 */
@@ -151,6 +151,32 @@ int list_prep_percep_proj(const void* img_map, int32_t img_dtype, int32_t B, int
                           size_t proj_bytes, void* scratch, size_t scratch_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * list_prep_img_proj (ABI 8) -- inference forwards at ANY number of query points: the same linearity, applied
+ * BEFORE the resize.  F.interpolate (network/modules.py:26-35) is linear per channel with the same weights for every
+ * channel, so for an encoder level l
+ *   sum_c fc_0.weight[n][c of level l] * resize(x_l)[b][c][y][x]  ==  resize(P_l)[b][n][y][x],
+ *   P_l[b][n][v][u] = sum_c fc_0.weight[n][c of level l] * x_l[b][c][v][u]       (H_l x W_l source pixels),
+ * and the projection costs H_l * W_l * C_l * H1 MACs per image instead of C_l * H1 per query point: 14^2 ... 56^2
+ * pixels against 20 000 points for the three low-resolution levels, which hold 896 of the 1024 perceptual channels.
+ * Levels 0 .. n_kept_levels-1 (the high-resolution ones, few channels) are resized as list_prep_img_maps does; the
+ * levels from n_kept_levels on are projected at their own resolution, resized and SUMMED.  Writes ONE channels-last
+ * map  out[B][map_size][map_size][kept_C + H1]  (kept_C = channels of the kept levels; fp16 elements for
+ * LIST_PREC_FP16, fp32 for the bf16 formats) for ListQueryArgs.img_proj = 1: per point the kept channels are sampled
+ * into the feature matrix as before, the H1 projected channels into an fp32 row vector that fc_0 adds in its
+ * epilogue, and fc_0's K loop leaves the projected levels' columns out.  Same arithmetic class as the MLP (operand
+ * format of `precision`, fp32 accumulate; P_l and the resized sum are fp32).  Valid while the maps and packed_mlp stay
+ * unchanged.  Finite maps (as list_prep_percep_proj).  kept_C % 64 == 0, every projected level's C % 64 == 0.
+ */
+size_t list_img_proj_map_bytes(const ListMap2D maps[LIST_N_IMG_LEVELS], int32_t B, int32_t map_size,
+                               int32_t n_kept_levels, int32_t H1, int32_t precision);
+size_t list_img_proj_scratch_bytes(const ListMap2D maps[LIST_N_IMG_LEVELS], int32_t B, int32_t n_kept_levels,
+                                   int32_t H1, int32_t precision);
+int list_prep_img_proj(const ListMap2D maps[LIST_N_IMG_LEVELS], int32_t B, int32_t map_size,
+                       int32_t n_kept_levels, const int32_t vox_C[LIST_N_VOX_LEVELS], const void* packed_mlp,
+                       int32_t H1, int32_t H2, int32_t H3, int32_t precision, void* out, size_t out_bytes,
+                       void* scratch, size_t scratch_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * list_sdf_query_fwd -- the fused hot path: LIST.forward lines network/models.py:91-97, i.e.
  * PerceptualPooling.forward (modules.py:37-53, on the prepared 137^2 map) +
  * VoxelDecoder2.forward (modules.py:255-282).  sdf[b][n] for every query point.
@@ -213,6 +239,11 @@ typedef struct ListQueryArgs {
                                         /*   and those columns of the feature matrix never reach HBM.  1:    */
                                         /*   the unfused pair (k_gather_img + k_gemm_nt_pp).  Same bits      */
                                         /*   either way (tests/test_fused_fc0_gpu.py).                       */
+  int32_t img_proj;                     /* ABI 8.  1: img_map is the output of list_prep_img_proj for packed_mlp: */
+  int32_t img_kept_C;                   /*   img_kept_C sampled channels followed by H1 projected ones per pixel  */
+                                        /*   (img_C stays the channel count of the feature layout, 1024).         */
+                                        /*   Inference only (no_activations = 1), percep_feat / percep_proj NULL. */
+                                        /*   0 (default): img_map is the output of list_prep_img_maps             */
 } ListQueryArgs;
 
 /* Boundaries recorded into ListQueryArgs.stage_events: one hipEvent after each kernel (group) of a
@@ -263,7 +294,7 @@ typedef struct ListQueryPlan {
                             /*    stencil stays inside one cell, 128 channels, fp16 maps and fp16 operands)           */
   int32_t fused_fc0;        /* 1: fc_0 produces the perceptual block of its A operand on chip (k_fc0_fused) and no 2-D   */
                             /*    gather kernel is launched; 0: k_gather_img writes the block into X                     */
-  int32_t reserved_[1];
+  int32_t img_proj;         /* 1: the projected levels' columns are left out of fc_0's K loop (ListQueryArgs.img_proj)      */
 } ListQueryPlan;
 int list_query_plan(const ListQueryArgs* args, ListQueryPlan* plan);
 

@@ -569,10 +569,12 @@ __device__ __forceinline__ void reduce_proj_exact(const typename M::Raw (&v)[4],
 // OUT32 (projected perceptual map, list_prep_percep_proj): the map holds H1 channels per pixel and the sample is
 // written as an fp32 row vector into the first bytes of the point's X row -- the perceptual block of X, which fc_0
 // then leaves out of its K loop and adds in its epilogue instead.  Out-of-map taps are masked like the reference.
+// `kept` (OUT32 only): the first `kept` channels of a pixel are sampled into X as without OUT32, the channels behind
+// them into the row vector (list_prep_img_proj: kept encoder levels | projected sum; list_prep_percep_proj: kept = 0).
 template <int FMT, int F16, int OUT32 = 0>
 __global__ __launch_bounds__(256) void k_gather_img(GatherParams g, const void* __restrict__ img_map,
                                                     const float* __restrict__ trans_mat, int ms,
-                                                    int Ct, float clamp_hi, int col_off) {
+                                                    int Ct, float clamp_hi, int col_off, int kept) {
   using M = MapT<F16>;
   using Raw = typename M::Raw;
   __shared__ ImgPoint ipt[kGatherRows];
@@ -628,13 +630,15 @@ __global__ __launch_bounds__(256) void k_gather_img(GatherParams g, const void* 
         const ImgPoint& a = ipt[pi];
         float r[M::V];
         if constexpr (OUT32) {
-          reduce_proj_exact<M>(v[k], a.pr, r);
-          float* dst = (float*)((char*)xh + (int64_t)a.row * g.Kp * (FMT == FMT_FP16 ? 2 : 4)) + q * M::V;
+          if (q * M::V >= kept) {
+            reduce_proj_exact<M>(v[k], a.pr, r);
+            float* dst = g.rowvec + (int64_t)a.row * g.rv_stride + (q * M::V - kept);
 #pragma unroll
-          for (int h = 0; h < M::V / 4; ++h)
-            *(float4*)(dst + 4 * h) = a.valid ? make_float4(r[4 * h], r[4 * h + 1], r[4 * h + 2], r[4 * h + 3])
-                                              : make_float4(0.f, 0.f, 0.f, 0.f);
-          continue;
+            for (int h = 0; h < M::V / 4; ++h)
+              *(float4*)(dst + 4 * h) = a.valid ? make_float4(r[4 * h], r[4 * h + 1], r[4 * h + 2], r[4 * h + 3])
+                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+          }
         }
         tap_mul<M>(v[k][0], a.pr.w00, r); tap_fma<M>(v[k][1], a.pr.w01, r);
         tap_fma<M>(v[k][2], a.pr.w10, r); tap_fma<M>(v[k][3], a.pr.w11, r);
@@ -749,6 +753,7 @@ __device__ __forceinline__ void write_xyz_and_pad(const GatherParams& g, const P
 struct FixupArgs {
   ListVoxLevel lv[LIST_N_VOX_LEVELS]; int off[LIST_N_VOX_LEVELS]; int n;     // vector voxel levels
   const void* img_map; const float* trans_mat; int img_f16, ms, Ct, img_off; float clamp_hi;   // img_map == NULL: none
+  int Cs;                                                                      // channels per pixel of img_map (Ct of them are sampled)
   const int* tile_flags;                                                       // [rows / 256]
 };
 
@@ -780,11 +785,11 @@ __device__ __forceinline__ void fixup_level(const GatherParams& g, const ListVox
 template <int FMT, typename M>
 __device__ __forceinline__ void fixup_img(const GatherParams& g, const FixupArgs& fa, int blk, const Pt* pts) {
   const int lq = fa.Ct / M::V;
-  const int64_t img_stride = (int64_t)fa.ms * fa.ms * fa.Ct;
+  const int64_t img_stride = (int64_t)fa.ms * fa.ms * fa.Cs;
   for (int item = threadIdx.x; item < kGatherRows * lq; item += 256) {
     const int local = item / lq, q = item - local * lq;
     const Pt p = pts[local];
-    const Proj pr = project(fa.trans_mat + p.b * 12, p.x, p.y, p.z, fa.ms, fa.Ct, fa.clamp_hi);
+    const Proj pr = project(fa.trans_mat + p.b * 12, p.x, p.y, p.z, fa.ms, fa.Cs, fa.clamp_hi);
     const int64_t bo = p.b * img_stride + q * M::V;
     const typename M::Raw v[4] = {M::load(fa.img_map, bo + pr.o00), M::load(fa.img_map, bo + pr.o01),
                                   M::load(fa.img_map, bo + pr.o10), M::load(fa.img_map, bo + pr.o11)};
@@ -820,6 +825,11 @@ hipError_t launch_gather_fixup(const GatherParams& g, const FeatLayout& L, const
     if (a.vox[l].C != 1) { fa.lv[fa.n] = a.vox[l]; fa.off[fa.n] = L.vox_off[l]; ++fa.n; }
   fa.img_map = (a.percep_feat || a.percep_proj) ? nullptr : a.img_map;     // (the projected sample is masked already)
   fa.trans_mat = a.trans_mat; fa.img_f16 = a.img_dtype == LIST_MAP_F16; fa.ms = a.map_size; fa.Ct = L.img_C;
+  fa.Cs = L.img_C;
+  if (a.img_proj) {               // only the kept levels' columns are part of X (the projected sample is masked already)
+    fa.Ct = a.img_kept_C; fa.Cs = a.img_kept_C + a.H1;
+    if (a.img_kept_C == 0) fa.img_map = nullptr;
+  }
   fa.img_off = L.img_off; fa.clamp_hi = a.clamp_hi; fa.tile_flags = tile_flags;
   if (g.fmt == FMT_FP16)
     hipLaunchKernelGGL(k_gather_fixup<FMT_FP16>, dim3(g.rows / kGatherRows), dim3(256), 0, s, g, fa);
@@ -928,19 +938,26 @@ static hipError_t launch_gather_fmt(const GatherParams& g, const FeatLayout& L, 
     if (a.percep_proj) {          // projected perceptual map: H1 channels, fp16 (fp16 operands) or fp32
       if (FMT == FMT_FP16)
         LIST_LAUNCH((k_gather_img<FMT, 1, 1>), dim3(g.rows / kGatherRows), dim3(256), 0, s, order, g, a.percep_proj,
-                    a.trans_mat, a.map_size, a.H1, a.clamp_hi, 0);
+                    a.trans_mat, a.map_size, a.H1, a.clamp_hi, 0, 0);
       else
         LIST_LAUNCH((k_gather_img<FMT, 0, 1>), dim3(g.rows / kGatherRows), dim3(256), 0, s, order, g, a.percep_proj,
-                    a.trans_mat, a.map_size, a.H1, a.clamp_hi, 0);
+                    a.trans_mat, a.map_size, a.H1, a.clamp_hi, 0, 0);
+    } else if (a.img_proj) {      // list_prep_img_proj: img_kept_C sampled channels | H1 projected ones per pixel
+      if (FMT == FMT_FP16)
+        LIST_LAUNCH((k_gather_img<FMT, 1, 1>), dim3(g.rows / kGatherRows), dim3(256), 0, s, order, g, a.img_map,
+                    a.trans_mat, a.map_size, a.img_kept_C + a.H1, a.clamp_hi, L.img_off, a.img_kept_C);
+      else
+        LIST_LAUNCH((k_gather_img<FMT, 0, 1>), dim3(g.rows / kGatherRows), dim3(256), 0, s, order, g, a.img_map,
+                    a.trans_mat, a.map_size, a.img_kept_C + a.H1, a.clamp_hi, L.img_off, a.img_kept_C);
     } else if (a.percep_feat) {
       LIST_LAUNCH(k_copy_percep<FMT>, dim3((g.rows + 255) / 256), dim3(256), 0, s, order, g,
                   a.percep_feat, a.pf_sb, a.pf_sc, a.pf_sn, L.img_C, L.img_off);
     } else if (a.img_dtype == LIST_MAP_F16) {
       LIST_LAUNCH((k_gather_img<FMT, 1>), dim3(g.rows / kGatherRows), dim3(256), 0, s, order, g, a.img_map,
-                  a.trans_mat, a.map_size, L.img_C, a.clamp_hi, L.img_off);
+                  a.trans_mat, a.map_size, L.img_C, a.clamp_hi, L.img_off, 0);
     } else {
       LIST_LAUNCH((k_gather_img<FMT, 0>), dim3(g.rows / kGatherRows), dim3(256), 0, s, order, g, a.img_map,
-                  a.trans_mat, a.map_size, L.img_C, a.clamp_hi, L.img_off);
+                  a.trans_mat, a.map_size, L.img_C, a.clamp_hi, L.img_off, 0);
     }
     return hipGetLastError();
   };

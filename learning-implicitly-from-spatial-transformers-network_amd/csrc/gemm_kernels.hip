@@ -684,11 +684,15 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_pp(GemmParams p) {
     return *(const bf16x8*)(cur + plane_off + row_off + blk * TR * P::kRowBytes + (((KO * ks + fo) ^ fswz) << 4));
   };
 
+  // byte offset of K-tile t in the operand rows: tiles from k_gap_at on lie k_gap tiles further (fc_0 without the projected
+  // levels of its perceptual block, list_prep_img_proj); scalar arithmetic, 0 / 0 = no gap
+  const int gap_at = p.k_gap_at, gap = p.k_gap;
+  auto ktb = [&](int t) { return (t + (t >= gap_at ? gap : 0)) * P::kRowBytes; };
   // prologue: quarters 0 .. kLead-1; the first K-tile must be complete for everybody; then the second wave
   // group falls one barrier behind
 #pragma unroll
   for (int g = 0; g < kLead; ++g)
-    if (g / 4 < nk) stage_quarter(smem + ((g / 4) & 1) * P::kStageBytes, (g / 4) * P::kRowBytes, g & 3);
+    if (g / 4 < nk) stage_quarter(smem + ((g / 4) & 1) * P::kStageBytes, ktb(g / 4), g & 3);
   if (nk > 1) wait_vmcnt<2 * (kLead - 4)>(); else wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();
@@ -722,11 +726,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_pp(GemmParams p) {
 #else
       if (STEADY) {
 #endif
-        stage_quarter(smem + (tt & 1) * P::kStageBytes, tt * P::kRowBytes, sq);
+        stage_quarter(smem + (tt & 1) * P::kStageBytes, ktb(tt), sq);
         wait_vmcnt<2 * (kLead - 2)>();     // my loads of every quarter up to k + 2 have landed
       } else {
 #ifndef LIST_PP_NO_LOAD
-        if (tt < nk) stage_quarter(smem + (tt & 1) * P::kStageBytes, tt * P::kRowBytes, sq);
+        if (tt < nk) stage_quarter(smem + (tt & 1) * P::kStageBytes, ktb(tt), sq);
 #endif
         const int beyond = last_quarter - (4 * t + ph + 2);        // quarters issued beyond k + 2
         if (beyond >= 4) wait_vmcnt<2 * (kLead - 2 < 4 ? kLead - 2 : 4)>();
@@ -1038,7 +1042,7 @@ static hipError_t launch_one(const GemmParams& p, hipStream_t s) {
   }
   if (p.x3i) return hipErrorInvalidValue;
   // operand strides, a row limit or a row vector exist in the ping-pong kernel only
-  const bool need_pp = p.lda || p.ldw || p.a_rows || p.rowvec;
+  const bool need_pp = p.lda || p.ldw || p.a_rows || p.rowvec || p.k_gap;
   // MFMA shape per epilogue (measured, fp16, P = 160k): 32x32x16 has the cheaper 64-B store runs on the short-K
   // layers (fc_1 0.074 vs 0.086 ms), 16x16x32 the cheaper row reduction of the fused fc_2 + fc_out epilogue (0.045
   // vs 0.058 ms) and, on the long-K ping-pong schedule, the higher clock (fc_0 0.55 -> 0.49 ms)

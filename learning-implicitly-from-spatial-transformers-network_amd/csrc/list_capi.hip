@@ -92,6 +92,29 @@ int check_query_common(const ListQueryArgs* a, FeatLayout* L) {
     if ((int64_t)a->map_size * a->map_size * a->img_C >= (int64_t)1 << 31)
       return fail(LIST_ERR_SHAPE, "image map larger than 2^31 elements");
   }
+  if (a->img_proj != 0 && a->img_proj != 1)
+    return fail(LIST_ERR_ARG, "img_proj=%d (0 or 1; zero-initialise ListQueryArgs, list_abi_version() = %d)", a->img_proj,
+                LIST_ABI_VERSION);
+  if (a->img_proj) {
+    // list_prep_img_proj's map: img_kept_C sampled channels | H1 projected ones; the row vector lives in the lo plane of
+    // X (fp16 operands: unused otherwise) or behind the kept columns of the row's perceptual block (split formats)
+    if (a->percep_feat || a->percep_proj) return fail(LIST_ERR_ARG, "img_proj excludes percep_feat / percep_proj");
+    if (!a->no_activations) return fail(LIST_ERR_ARG, "img_proj is an inference path: set no_activations = 1");
+    const int xbytes = a->precision == LIST_PREC_FP16 ? 2 : 4;
+    const int ktile = a->precision == LIST_PREC_FP16 ? 64 : 32;            // columns per 128-byte K-tile of X
+    if (a->img_kept_C < 0 || a->img_kept_C >= a->img_C || a->img_kept_C % 64 || a->img_C % ktile || a->H1 % 8)
+      return fail(LIST_ERR_UNSUPPORTED, "img_proj needs 0 <= img_kept_C < img_C, img_kept_C %% 64 == 0, H1 %% 8 == 0 "
+                                        "(img_kept_C=%d, img_C=%d, H1=%d)", a->img_kept_C, a->img_C, a->H1);
+    if (xbytes == 4 && (int64_t)(a->img_kept_C + a->H1) * 4 > (int64_t)a->img_C * 4)
+      return fail(LIST_ERR_UNSUPPORTED, "img_proj: img_kept_C + H1 must fit the perceptual block (%d + %d > %d)",
+                  a->img_kept_C, a->H1, a->img_C);
+    if ((int64_t)a->map_size * a->map_size * (a->img_kept_C + a->H1) >= (int64_t)1 << 31)
+      return fail(LIST_ERR_SHAPE, "projected map larger than 2^31 elements");
+    if ((a->precision == LIST_PREC_FP16) != (a->img_dtype == LIST_MAP_F16))
+      return fail(LIST_ERR_UNSUPPORTED, "img_proj: fp16 operands pair with fp16 maps, the bf16 formats with fp32 maps");
+  } else if (a->img_kept_C != 0) {
+    return fail(LIST_ERR_ARG, "img_kept_C=%d without img_proj", a->img_kept_C);
+  }
   if (a->percep_proj) {
     // the projected sample (H1 floats) lives in the perceptual block of the point's X row; fc_0 starts behind it
     if (a->percep_feat) return fail(LIST_ERR_ARG, "percep_proj and percep_feat exclude each other");
@@ -117,6 +140,15 @@ GatherParams make_gather(const ListQueryArgs* a, const FeatLayout& L, const Work
   g.Kp = L.Kp;
   g.fmt = a->precision == LIST_PREC_FP16 ? FMT_FP16 : FMT_BF16_SPLIT;
   g.order = nullptr; g.order_img = nullptr; g.row_of = nullptr;
+  // where the projected perceptual sample (H1 floats per row) goes; fc_0's epilogue reads it from there
+  g.rowvec = nullptr; g.rv_stride = 0;
+  const int xb = a->precision == LIST_PREC_FP16 ? 2 : 4;
+  if (a->percep_proj) {                      // the head of the row's perceptual block
+    g.rowvec = (float*)g.x_hi; g.rv_stride = (int64_t)L.Kp * xb / 4;
+  } else if (a->img_proj) {
+    if (xb == 2) { g.rowvec = (float*)g.x_lo; g.rv_stride = a->H1; }                 // the lo plane: rows * Kp * 2 >= rows * H1 * 4
+    else { g.rowvec = (float*)g.x_hi + a->img_kept_C; g.rv_stride = (int64_t)L.Kp; }  // behind the kept columns (4 B per column)
+  }
   return g;
 }
 
@@ -154,7 +186,7 @@ int fused_fc0_mode() {
 }
 bool takes_fused_fc0_any(const ListQueryArgs* a, const FeatLayout& L) {
   if (fused_fc0_mode() == 0) return false;
-  if (a->percep_feat || a->percep_proj) return false;
+  if (a->percep_feat || a->percep_proj || a->img_proj) return false;
   // fp16 operands with fp16 maps, the bf16 formats with fp32 maps (the pairs the standard path takes too)
   if ((a->precision == LIST_PREC_FP16) != (a->img_dtype == LIST_MAP_F16)) return false;
   // bf16x3 keeps the unfused path: its packed weight is twice as long (hi + lo), and a 128-row tile streams ALL of it
@@ -419,6 +451,116 @@ int list_prep_percep_proj(const void* img_map, int32_t img_dtype, int32_t B, int
   return LIST_OK;
 }
 
+// ------------------------------------------------------------------------------------------ projected encoder levels
+namespace {
+struct ImgProjPlan {
+  int kept_C, img_C, n_proj;
+  int64_t rows[LIST_N_IMG_LEVELS], rows_pad[LIST_N_IMG_LEVELS];        // B * H * W of a projected level (padded to 256)
+  size_t a_f32[LIST_N_IMG_LEVELS], a_op[LIST_N_IMG_LEVELS], p[LIST_N_IMG_LEVELS];   // scratch offsets: rows (fp32 staging, split
+  size_t scratch;                                                      //   formats only), operand rows, projected level
+};
+int img_proj_plan(const ListMap2D* maps, int32_t B, int32_t n_kept, int32_t H1, int32_t precision, ImgProjPlan* pl) {
+  if (!maps) return fail(LIST_ERR_ARG, "maps is NULL");
+  if (precision < LIST_PREC_BF16X3 || precision > LIST_PREC_FP16) return fail(LIST_ERR_ARG, "precision=%d", precision);
+  if (B <= 0 || B > 65535) return fail(LIST_ERR_SHAPE, "B=%d", B);
+  if (n_kept < 0 || n_kept >= LIST_N_IMG_LEVELS)
+    return fail(LIST_ERR_ARG, "n_kept_levels=%d (need 0 .. %d: at least one level is projected)", n_kept, LIST_N_IMG_LEVELS - 1);
+  if (H1 <= 0 || H1 % 256) return fail(LIST_ERR_UNSUPPORTED, "H1=%d (need a multiple of 256)", H1);
+  const bool fp16 = precision == LIST_PREC_FP16;
+  pl->kept_C = 0; pl->img_C = 0; pl->n_proj = LIST_N_IMG_LEVELS - n_kept;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+  for (int i = 0; i < LIST_N_IMG_LEVELS; ++i) {
+    const ListMap2D& m = maps[i];
+    if (!m.data || m.C < 1 || m.H < 1 || m.W < 1) return fail(LIST_ERR_SHAPE, "image level %d: bad descriptor", i);
+    if (m.C % 64) return fail(LIST_ERR_UNSUPPORTED, "image level %d: C=%d (img_proj needs multiples of 64)", i, m.C);
+    pl->img_C += m.C;
+    if (i < n_kept) { pl->kept_C += m.C; continue; }
+    const int64_t rows = (int64_t)B * m.H * m.W;
+    if (rows * (m.C > H1 ? m.C : H1) >= (int64_t)1 << 31) return fail(LIST_ERR_SHAPE, "image level %d: too large to project", i);
+    pl->rows[i] = rows; pl->rows_pad[i] = (rows + kRowTile - 1) / kRowTile * kRowTile;
+    pl->a_f32[i] = fp16 ? 0 : take((size_t)rows * m.C * 4);
+    pl->a_op[i] = take((size_t)rows * m.C * (fp16 ? 2 : 4));
+    pl->p[i] = take((size_t)pl->rows_pad[i] * H1 * 4);
+  }
+  pl->scratch = o;
+  return LIST_OK;
+}
+}  // namespace
+
+size_t list_img_proj_map_bytes(const ListMap2D maps[LIST_N_IMG_LEVELS], int32_t B, int32_t map_size,
+                               int32_t n_kept_levels, int32_t H1, int32_t precision) {
+  ImgProjPlan pl;
+  if (map_size < 2 || img_proj_plan(maps, B, n_kept_levels, H1, precision, &pl) != LIST_OK) return 0;
+  return (size_t)B * map_size * map_size * (pl.kept_C + H1) * (precision == LIST_PREC_FP16 ? 2 : 4);
+}
+
+size_t list_img_proj_scratch_bytes(const ListMap2D maps[LIST_N_IMG_LEVELS], int32_t B, int32_t n_kept_levels,
+                                   int32_t H1, int32_t precision) {
+  ImgProjPlan pl;
+  if (img_proj_plan(maps, B, n_kept_levels, H1, precision, &pl) != LIST_OK) return 0;
+  return pl.scratch;
+}
+
+int list_prep_img_proj(const ListMap2D maps[LIST_N_IMG_LEVELS], int32_t B, int32_t map_size,
+                       int32_t n_kept_levels, const int32_t vox_C[LIST_N_VOX_LEVELS], const void* packed_mlp,
+                       int32_t H1, int32_t H2, int32_t H3, int32_t precision, void* out, size_t out_bytes,
+                       void* scratch, size_t scratch_bytes, void* stream) {
+  if (!vox_C || !packed_mlp || !out || !scratch) return fail(LIST_ERR_ARG, "NULL pointer");
+  if (map_size < 2 || map_size > 320) return fail(LIST_ERR_SHAPE, "map_size=%d (need 2..320)", map_size);
+  ImgProjPlan pl;
+  int rc = img_proj_plan(maps, B, n_kept_levels, H1, precision, &pl);
+  if (rc != LIST_OK) return rc;
+  FeatLayout L;
+  if (!make_layout(vox_C, pl.img_C, &L)) return fail(LIST_ERR_UNSUPPORTED, "unsupported channel counts");
+  if (L.img_off != 0) return fail(LIST_ERR_ARG, "internal: the perceptual block does not lead the feature layout");
+  const bool fp16 = precision == LIST_PREC_FP16;
+  if (!aligned16(packed_mlp) || !aligned16(out) || !aligned16(scratch)) return fail(LIST_ERR_SHAPE, "buffers must be 16-byte aligned");
+  const size_t need_out = list_img_proj_map_bytes(maps, B, map_size, n_kept_levels, H1, precision);
+  if (out_bytes < need_out) return fail(LIST_ERR_WORKSPACE, "out buffer too small: %zu < %zu", out_bytes, need_out);
+  if (scratch_bytes < pl.scratch) return fail(LIST_ERR_WORKSPACE, "scratch too small: %zu < %zu", scratch_bytes, pl.scratch);
+  if ((int64_t)map_size * map_size * (pl.kept_C + H1) >= (int64_t)1 << 31) return fail(LIST_ERR_SHAPE, "projected map larger than 2^31 elements");
+  const PackedMlp pk = packed_mlp_layout(L.Kp, H1, H2, H3);
+  if (!fp16 && pk.w0_lo != pk.w0_hi + (size_t)H1 * L.Kp * 2)
+    return fail(LIST_ERR_ARG, "internal: hi / lo planes of the packed fc_0 weight are not contiguous");
+  hipStream_t s = (hipStream_t)stream;
+  const int Ct = pl.kept_C + H1;
+  hipError_t e = launch_prep_img(maps, B, map_size, Ct, fp16 ? 1 : 0, out, s, n_kept_levels);
+  if (e != hipSuccess) return hip_fail(e, "prep_img launch");
+  ListMap2D proj[LIST_N_IMG_LEVELS];
+  int coff = pl.kept_C, n_proj = 0;
+  for (int i = n_kept_levels; i < LIST_N_IMG_LEVELS; ++i) {
+    const ListMap2D& m = maps[i];
+    char* sc = (char*)scratch;
+    // rows [B*H*W][C] in the operand format (fp16, or bf16 hi / lo interleaved through an fp32 staging copy)
+    e = launch_img_level_rows(m, B, fp16 ? 1 : 0, fp16 ? sc + pl.a_op[i] : sc + pl.a_f32[i], s);
+    if (e != hipSuccess) return hip_fail(e, "level rows launch");
+    if (!fp16) {
+      e = launch_split_xi((const float*)(sc + pl.a_f32[i]), (unsigned short*)(sc + pl.a_op[i]), pl.rows[i] * m.C, s);
+      if (e != hipSuccess) return hip_fail(e, "level split launch");
+    }
+    // P_l[pixel][n] = sum_c rows[pixel][c] * W0[n][coff + c]  (fp32 out)
+    GemmParams gp;
+    memset(&gp, 0, sizeof(gp));
+    gp.fmt = fp16 ? FMT_FP16 : FMT_BF16_SPLIT;
+    gp.x3i = fp16 ? 0 : 1;
+    gp.a_hi = sc + pl.a_op[i]; gp.a_lo = gp.a_hi;
+    gp.w_hi = (const char*)packed_mlp + pk.w0_hi + (size_t)coff * (fp16 ? 2 : 4); gp.w_lo = gp.w_hi;
+    gp.M = (int)pl.rows_pad[i]; gp.N = H1; gp.K = m.C;
+    gp.lda = m.C; gp.ldw = L.Kp; gp.a_rows = (int)pl.rows[i];
+    gp.dx = sc + pl.p[i]; gp.dx_f16 = 0; gp.n_store = H1; gp.ldo = H1;
+    e = launch_gemm(gp, precision == LIST_PREC_BF16X3 ? 3 : 1, EPI_DX, s);
+    if (e != hipSuccess) return hip_fail(e, "level projection launch");
+    ListMap2D& pm = proj[n_proj++];
+    pm.data = (const float*)(sc + pl.p[i]); pm.C = H1; pm.H = m.H; pm.W = m.W;
+    pm.sc = 1; pm.sw = H1; pm.sh = (int64_t)m.W * H1; pm.sb = (int64_t)m.H * m.W * H1;
+    coff += m.C;
+  }
+  e = launch_proj_resize_sum(proj, n_proj, B, map_size, Ct, pl.kept_C, fp16 ? 1 : 0, out, s);
+  if (e != hipSuccess) return hip_fail(e, "projected resize launch");
+  return LIST_OK;
+}
+
 int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
   FeatLayout L;
   if (a && a->B >= 0 && a->N >= 0 && (int64_t)a->B * a->N == 0) return LIST_OK;   // empty query: nothing to do
@@ -505,6 +647,14 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
       gp.a_hi += skip; gp.w_hi += skip;
       gp.K = L.Kp - a->img_C; gp.lda = L.Kp; gp.ldw = L.Kp;
       gp.rowvec = wsb + ws.x_hi; gp.rowvec_stride = (int64_t)L.Kp * (gp.x3i ? 4 : 2);
+    } else if (a->img_proj) {
+      // the projected levels' columns (img_kept_C .. img_C of the perceptual block, which leads the rows) are left out
+      // of the K loop: their contribution is the row vector the 2-D gather sampled from the projected channels
+      const int ktile = gp.x3i ? 32 : 64;                   // columns per 128-byte K-tile
+      gp.k_gap_at = a->img_kept_C / ktile; gp.k_gap = (a->img_C - a->img_kept_C) / ktile;
+      gp.K = L.Kp - (a->img_C - a->img_kept_C); gp.lda = L.Kp; gp.ldw = L.Kp;
+      gp.rowvec = (const char*)g.rowvec; gp.rowvec_stride = g.rv_stride * 4;
+      if (a->H1 * 4 > L.Kp * 2) return fail(LIST_ERR_UNSUPPORTED, "img_proj: H1 * 4 bytes exceed a row of the feature matrix's lo plane");
     }
     gp.out_hi = (unsigned short*)(wsb + ws.h1_hi);
     gp.out_lo = terms == 3 ? (unsigned short*)(wsb + ws.h1_lo) : nullptr;
@@ -533,7 +683,7 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
     e = launch_gemm(gp, terms, EPI_RELU_SPLIT, s);
     if (e != hipSuccess) return hip_fail(e, "gated fc_0 launch");
     gp.tile_gate = nullptr; gp.x3i = 0;
-    gp.lda = gp.ldw = 0; gp.rowvec = nullptr;
+    gp.lda = gp.ldw = 0; gp.rowvec = nullptr; gp.k_gap_at = gp.k_gap = 0;
     mark(LIST_STAGE_EXACT);
     // fc_1 + ReLU
     gp.a_hi = wsb + ws.h1_hi; gp.a_lo = wsb + ws.h1_lo;
@@ -590,7 +740,8 @@ int list_query_plan(const ListQueryArgs* a, ListQueryPlan* plan) {
   plan->rows_per_chunk = rows;
   plan->chunks = (int32_t)((P + rows - 1) / rows);
   plan->fused_tail = takes_fused_tail(a) ? 1 : 0;
-  plan->fc0_k = a->percep_proj ? L.Kp - a->img_C : L.Kp;
+  plan->fc0_k = a->percep_proj ? L.Kp - a->img_C : a->img_proj ? L.Kp - (a->img_C - a->img_kept_C) : L.Kp;
+  plan->img_proj = a->img_proj ? 1 : 0;
   {
     const Workspace ws = workspace_layout(rows, L.Kp, a->H1, a->H2);
     const int n_valid = (int)(P < rows ? P : rows);
@@ -606,7 +757,7 @@ int list_gather_features_fwd(const ListQueryArgs* a, float* out, void* stream) {
   int rc = check_query_common(a, &L);
   if (rc != LIST_OK) return rc;
   if (!out) return fail(LIST_ERR_ARG, "out is NULL");
-  if (a->percep_proj) return fail(LIST_ERR_UNSUPPORTED, "percep_proj leaves the perceptual features out of X");
+  if (a->percep_proj || a->img_proj) return fail(LIST_ERR_UNSUPPORTED, "percep_proj / img_proj leave perceptual features out of X");
   const int64_t P = (int64_t)a->B * a->N;
   const int H1 = a->H1 > 0 ? a->H1 : 512, H2 = a->H2 > 0 ? a->H2 : 256;
   const int64_t rows = chunk_rows_for(a->workspace_bytes, P, L.Kp, H1, H2);
@@ -720,6 +871,7 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
     return fail(LIST_ERR_ARG, "precision=%d", a->precision);
   if (ga->vox_adjoint < 0 || ga->vox_adjoint > 2) return fail(LIST_ERR_ARG, "vox_adjoint=%d", ga->vox_adjoint);
   if (a->percep_proj) return fail(LIST_ERR_UNSUPPORTED, "a forward with percep_proj (inference) keeps no perceptual features for the backward");
+  if (a->img_proj) return fail(LIST_ERR_UNSUPPORTED, "a forward with img_proj (inference) keeps no perceptual features for the backward");
   if (a->no_activations) return fail(LIST_ERR_ARG, "a forward with no_activations = 1 (inference) keeps no H1 / H2 for the backward");
   const int64_t P = (int64_t)a->B * a->N;
   if (P > kMaxChunkRows)

@@ -403,6 +403,7 @@ struct GatherParams {
   const int* order;           // row -> chunk-local point index (Morton order), or nullptr
   const int* order_img;       // 2-D gather: slot -> chunk-local point index (pixel order), or nullptr
   const int* row_of;          // chunk-local point index -> X row (inverse of `order`)
+  float* rowvec; int64_t rv_stride;   // projected perceptual sample: fp32 [rows][H1] row vectors (stride in floats), or null
 };
 
 struct GemmParams {
@@ -425,6 +426,9 @@ struct GemmParams {
   int lda, ldw;                                              // row strides of A / W in elements (0: K)
   int a_rows;                                                // rows of A that exist (0: M); staging re-reads the last one beyond
   const char* rowvec; int64_t rowvec_stride;                 // EPI_RELU_SPLIT: fp32 [M][N] row vectors added before the ReLU (byte stride), or null
+  int k_gap_at, k_gap;                                       // K-tiles (128 operand bytes per row) k_gap_at .. are read k_gap tiles further on in
+                                                             //   A and W: fc_0 without the PROJECTED levels of its perceptual block
+                                                             //   (list_prep_img_proj); K counts the tiles that are read.  0 / 0: none
 };
 
 // EPI_MASK_SPLIT: out = acc where the saved activation is positive (ReLU backward), no bias;
@@ -443,8 +447,15 @@ struct GemmTnParams {
 };
 
 // ---- launchers (defined in the .hip files) ----------------------------------------------------
+// n_levels: the first n_levels maps are resized into channels [0, sum C) of a map with Ct channels per pixel
 hipError_t launch_prep_img(const ListMap2D maps[LIST_N_IMG_LEVELS], int B, int map_size, int Ct,
-                           int f16, void* out, hipStream_t s);
+                           int f16, void* out, hipStream_t s, int n_levels = LIST_N_IMG_LEVELS);
+// list_prep_img_proj (prep_kernels.hip): encoder level [B,C,H,W] fp32 (any strides) -> rows [B*H*W][C], fp16 or fp32
+hipError_t launch_img_level_rows(const ListMap2D& m, int B, int f16, void* out, hipStream_t s);
+// out[b][y][x][coff + n] = sum_l resize(P_l)[b][y][x][n]: P_l = channels-last fp32 [B][H_l][W_l][H1] (n_src of them),
+// out = map with Ct channels per pixel (fp16 or fp32 elements); H1 % 64 == 0
+hipError_t launch_proj_resize_sum(const ListMap2D* src, int n_src, int B, int map_size, int Ct, int coff, int f16,
+                                  void* out, hipStream_t s);
 hipError_t launch_transpose_vox(const ListMap3D& m, int B, int f16, void* out, hipStream_t s);
 // the levels for which transpose_tile_eligible() holds, all in one launch
 bool transpose_tile_eligible(const ListMap3D& m, const void* out);

@@ -416,8 +416,9 @@ static bool rows_eligible(const ListMap2D& m, int ms, int Ct, int coff) {
 }
 
 hipError_t launch_prep_img(const ListMap2D maps[LIST_N_IMG_LEVELS], int B, int map_size, int Ct,
-                           int f16, void* out, hipStream_t s) {
+                           int f16, void* out, hipStream_t s, int n_levels) {
   int coff = 0;
+  if (n_levels <= 0) return hipSuccess;
 #ifndef LIST_PREP_IMG_NO_ROWS
   {
     PrepRowsArgs a;
@@ -426,7 +427,7 @@ hipError_t launch_prep_img(const ListMap2D maps[LIST_N_IMG_LEVELS], int B, int m
     int64_t wgs = 0;
     bool all = true;
     int co = 0;
-    for (int i = 0; i < LIST_N_IMG_LEVELS; ++i) {
+    for (int i = 0; i < n_levels; ++i) {
       const ListMap2D& m = maps[i];
       if (!rows_eligible(m, map_size, Ct, co)) { all = false; break; }
       PrepRowsLevel& lv = a.lv[a.n_levels++];
@@ -467,7 +468,7 @@ hipError_t launch_prep_img(const ListMap2D maps[LIST_N_IMG_LEVELS], int B, int m
     }
   }
 #endif
-  for (int i = 0; i < LIST_N_IMG_LEVELS; ++i) {
+  for (int i = 0; i < n_levels; ++i) {
     const ListMap2D& m = maps[i];
     hipError_t fe = hipSuccess;
     if (try_prep_img_nhwc(m, B, map_size, Ct, coff, f16, out, s, &fe) ||
@@ -483,6 +484,173 @@ hipError_t launch_prep_img(const ListMap2D maps[LIST_N_IMG_LEVELS], int B, int m
     coff += m.C;
   }
   return hipSuccess;
+}
+
+// --------------------------------------------------------------------------------------------
+// list_prep_img_proj: an encoder level [B,C,H,W] fp32 (any strides) -> the A operand of its projection, rows
+// [B*H*W][C] (fp16, or fp32 for the split formats).  The levels this runs on are small (14^2 ... 56^2 pixels,
+// 3 - 13 MB per batch): lanes over pixels (coalesced along W on NCHW sources), 8 channels per thread.
+// grid = (ceil(H*W / 64), C / 8, B); block = 64.
+// --------------------------------------------------------------------------------------------
+template <int F16>
+__global__ __launch_bounds__(64) void k_img_level_rows(ListMap2D m, void* __restrict__ out) {
+  const int px = blockIdx.x * 64 + threadIdx.x;
+  const int npx = m.H * m.W;
+  if (px >= npx) return;
+  const int y = px / m.W, x = px - y * m.W;
+  const int c0 = blockIdx.y * 8, b = blockIdx.z;
+  const float* src = m.data + (int64_t)b * m.sb + (int64_t)y * m.sh + (int64_t)x * m.sw + (int64_t)c0 * m.sc;
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = src[(int64_t)k * m.sc];
+  const int64_t o = ((int64_t)b * npx + px) * m.C + c0;
+  if (F16) {
+    const uint2 lo = half4(make_float4(v[0], v[1], v[2], v[3])), hi = half4(make_float4(v[4], v[5], v[6], v[7]));
+    *(uint4*)((unsigned short*)out + o) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  } else {
+    *(float4*)((float*)out + o) = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)((float*)out + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
+
+hipError_t launch_img_level_rows(const ListMap2D& m, int B, int f16, void* out, hipStream_t s) {
+  if (m.C % 8 || m.H < 1 || m.W < 1 || B < 1 || B > 65535 || m.C / 8 > 65535) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)((m.H * m.W + 63) / 64), (unsigned)(m.C / 8), (unsigned)B);
+  if (f16) hipLaunchKernelGGL(k_img_level_rows<1>, grid, dim3(64), 0, s, m, out);
+  else hipLaunchKernelGGL(k_img_level_rows<0>, grid, dim3(64), 0, s, m, out);
+  return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------------------
+// list_prep_img_proj: out[b][y][x][coff + n] = sum_l resize(P_l)[b][y][x][n] -- the bilinear align_corners resize of
+// k_prep_img_rows (same index and weight arithmetic, same separable order, same row-streaming scheme: a thread owns
+// (output column, 8 channels) and walks down its rows with the two horizontally interpolated source rows of EVERY
+// source level in registers), the levels' results added in level order in fp32.  The sources are the projected
+// levels, channels-last fp32 [B][H_l][W_l][H1]: 8 channels of a tap are 32 contiguous bytes.
+// --------------------------------------------------------------------------------------------
+constexpr int kProjMaxSrc = LIST_N_IMG_LEVELS;
+struct ProjSumArgs { ListMap2D src[kProjMaxSrc]; int n_src, B, ms, Ct, coff, H1, RY, nyt, nxt; };
+
+template <int F16>
+__global__ __launch_bounds__(LIST_PREP_THREADS) void k_proj_resize_sum(ProjSumArgs a, void* __restrict__ out) {
+  const int bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int cgroups = a.H1 / kRowsCg;
+  int idx = bid;
+  const int xt = idx % a.nxt; idx /= a.nxt;
+  const int cg = idx % cgroups; idx /= cgroups;
+  const int yt = idx % a.nyt;
+  const int b = idx / a.nyt;
+  const int ms = a.ms;
+  const int q = threadIdx.x & 7, xi = threadIdx.x >> 3;
+  const int xo = xt * kRowsPx + xi;
+  const bool active = xo < ms;
+  const int x = active ? xo : ms - 1;
+  const int c = cg * kRowsCg + 8 * q;
+
+  float top[kProjMaxSrc][8], bot[kProjMaxSrc][8];
+  int row_top[kProjMaxSrc], row_bot[kProjMaxSrc];
+  const float* p0[kProjMaxSrc]; const float* p1[kProjMaxSrc];
+  float wx0[kProjMaxSrc], wx1[kProjMaxSrc], sy[kProjMaxSrc];
+#pragma unroll
+  for (int l = 0; l < kProjMaxSrc; ++l) {
+    if (l >= a.n_src) break;
+    const ListMap2D& m = a.src[l];
+    sy[l] = ms > 1 ? (float)(m.H - 1) / (float)(ms - 1) : 0.f;
+    const float sx = ms > 1 ? (float)(m.W - 1) / (float)(ms - 1) : 0.f;
+    const float fx = sx * (float)x;
+    const int x0 = min((int)fx, m.W - 1);
+    const int x1 = x0 + (x0 < m.W - 1 ? 1 : 0);
+    wx1[l] = fx - (float)x0; wx0[l] = 1.f - wx1[l];
+    p0[l] = m.data + (int64_t)b * m.sb + (int64_t)x0 * m.sw + c;
+    p1[l] = m.data + (int64_t)b * m.sb + (int64_t)x1 * m.sw + c;
+    row_top[l] = -1; row_bot[l] = -1;
+  }
+  auto hrow = [&](int l, int r, float (&h)[8]) {
+    const float* r0 = p0[l] + (int64_t)r * a.src[l].sh;
+    const float* r1 = p1[l] + (int64_t)r * a.src[l].sh;
+    const float4 a0 = *(const float4*)r0, a1 = *(const float4*)(r0 + 4);
+    const float4 b0 = *(const float4*)r1, b1 = *(const float4*)(r1 + 4);
+    const float u[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const float v[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) h[k] = u[k] * wx0[l] + v[k] * wx1[l];
+  };
+
+  const int y_first = yt * a.RY, y_end = min(y_first + a.RY, ms);
+  int64_t oi = ((int64_t)(b * ms + y_first) * ms + xo) * a.Ct + a.coff + c;
+  const int64_t ostep = (int64_t)ms * a.Ct;
+#pragma unroll 1
+  for (int y = y_first; y < y_end; ++y, oi += ostep) {
+    float o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = 0.f;
+#pragma unroll
+    for (int l = 0; l < kProjMaxSrc; ++l) {
+      if (l >= a.n_src) break;
+      const int H = a.src[l].H;
+      const float fy = sy[l] * (float)y;
+      const int y0 = min((int)fy, H - 1);
+      const int y1 = y0 + (y0 < H - 1 ? 1 : 0);
+      const float wy1 = fy - (float)y0, wy0 = 1.f - wy1;
+      if (y0 != row_top[l]) {                    // (wave-uniform: y is the same for the workgroup)
+        if (y0 == row_bot[l]) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) top[l][k] = bot[l][k];
+        } else {
+          hrow(l, y0, top[l]);
+        }
+        row_top[l] = y0;
+      }
+      if (y1 != row_bot[l]) {
+        if (y1 == row_top[l]) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) bot[l][k] = top[l][k];
+        } else {
+          hrow(l, y1, bot[l]);
+        }
+        row_bot[l] = y1;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] += top[l][k] * wy0 + bot[l][k] * wy1;
+    }
+    if (!active) continue;
+    if (F16) {
+      const uint2 lo = half4(make_float4(o[0], o[1], o[2], o[3]));
+      const uint2 hi = half4(make_float4(o[4], o[5], o[6], o[7]));
+      *(uint4*)((unsigned short*)out + oi) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    } else {
+      *(float4*)((float*)out + oi) = make_float4(o[0], o[1], o[2], o[3]);
+      *(float4*)((float*)out + oi + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+  }
+}
+
+hipError_t launch_proj_resize_sum(const ListMap2D* src, int n_src, int B, int map_size, int Ct, int coff, int f16,
+                                  void* out, hipStream_t s) {
+  if (n_src < 1 || n_src > kProjMaxSrc || map_size < 2 || B < 1) return hipErrorInvalidValue;
+  ProjSumArgs a;
+  a.n_src = n_src; a.B = B; a.ms = map_size; a.Ct = Ct; a.coff = coff; a.H1 = src[0].C;
+  if (a.H1 % kRowsCg || coff % 8 || Ct % 8) return hipErrorInvalidValue;
+  float sy_max = 0.f;
+  for (int l = 0; l < n_src; ++l) {
+    const ListMap2D& m = src[l];
+    if (m.C != a.H1 || m.sc != 1 || (m.sw % 4) || (m.sh % 4) || (m.sb % 4) || (reinterpret_cast<uintptr_t>(m.data) & 15))
+      return hipErrorInvalidValue;
+    a.src[l] = m;
+    const float sy = (float)(m.H - 1) / (float)(map_size - 1);
+    sy_max = sy > sy_max ? sy : sy_max;
+  }
+  for (int l = n_src; l < kProjMaxSrc; ++l) a.src[l] = src[0];
+  // output rows per workgroup: about five fetches of the finest source level per workgroup (k_prep_img_rows's rule)
+  int ry = (int)(3.3f / (sy_max > 0.05f ? sy_max : 0.05f) + 0.5f);
+  a.RY = ry < 2 ? 2 : (ry > LIST_PREP_RY_MAX ? LIST_PREP_RY_MAX : ry);
+  a.nyt = (map_size + a.RY - 1) / a.RY;
+  a.nxt = (map_size + kRowsPx - 1) / kRowsPx;
+  const int64_t wgs = (int64_t)B * a.nyt * (a.H1 / kRowsCg) * a.nxt;
+  if (wgs <= 0 || wgs >= 2147483647LL) return hipErrorInvalidValue;
+  if (f16) hipLaunchKernelGGL(k_proj_resize_sum<1>, dim3((unsigned)wgs), dim3(kRowsPx * 8), 0, s, a, out);
+  else hipLaunchKernelGGL(k_proj_resize_sum<0>, dim3((unsigned)wgs), dim3(kRowsPx * 8), 0, s, a, out);
+  return hipGetLastError();
 }
 
 // --------------------------------------------------------------------------------------------

@@ -72,7 +72,7 @@ class ListQueryArgs(C.Structure):
                 ("precision", C.c_int32),
                 ("stage_events", C.POINTER(C.c_void_p)), ("no_sort", C.c_int32),
                 ("stage_event_sets", C.c_int32), ("percep_proj", C.c_void_p), ("no_activations", C.c_int32),
-                ("no_fused_fc0", C.c_int32)]
+                ("no_fused_fc0", C.c_int32), ("img_proj", C.c_int32), ("img_kept_C", C.c_int32)]
 
 
 class ListMlpGrads(C.Structure):
@@ -122,7 +122,7 @@ class ListPoolGradArgs(C.Structure):
 class ListQueryPlan(C.Structure):
     _fields_ = [("rows_per_chunk", C.c_int64), ("chunks", C.c_int32), ("fused_tail", C.c_int32),
                 ("fc0_k", C.c_int32), ("box_levels", C.c_int32), ("fused_fc0", C.c_int32),
-                ("reserved_", C.c_int32 * 1)]
+                ("img_proj", C.c_int32)]
 
 
 EXPORTS = {
@@ -137,6 +137,11 @@ EXPORTS = {
     "list_prep_percep_proj": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32,
                                         C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                         C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "list_img_proj_map_bytes": (C.c_size_t, [C.POINTER(ListMap2D), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "list_img_proj_scratch_bytes": (C.c_size_t, [C.POINTER(ListMap2D), C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "list_prep_img_proj": (C.c_int, [C.POINTER(ListMap2D), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
+                                     C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
+                                     C.c_void_p, C.c_size_t, C.c_void_p]),
     "list_packed_mlp_bytes": (C.c_size_t, [C.POINTER(ListMlpWeights)]),
     "list_prep_mlp_weights": (C.c_int, [C.POINTER(ListMlpWeights), C.c_void_p, C.c_size_t,
                                         C.c_void_p]),
@@ -171,7 +176,7 @@ _lib = None
 _lock = threading.Lock()
 
 
-ABI_VERSION = 7          # LIST_ABI_VERSION of the include/list_hip.h these ctypes structs mirror (checked in load())
+ABI_VERSION = 8          # LIST_ABI_VERSION of the include/list_hip.h these ctypes structs mirror (checked in load())
 
 
 def load():
@@ -229,10 +234,15 @@ def _f32_cuda(t, name):
 
 # ------------------------------------------------------------------------------------------------
 class PreparedImage:
-    """Channels-last resized perceptual map [B,ms,ms,Ct], float32 or float16."""
+    """Channels-last resized perceptual map [B,ms,ms,Ct], float32 or float16.
 
-    def __init__(self, data, map_size, channels, dtype):
+    kept_C is not None: the output of prep_img_proj -- [B,ms,ms,kept_C + H1]: the first kept_C channels are the resized
+    high-resolution encoder levels, the H1 behind them the low-resolution levels projected through fc_0 (valid for
+    `packed` only); `channels` stays the channel count of the feature layout (1024)."""
+
+    def __init__(self, data, map_size, channels, dtype, kept_C=None, packed=None):
         self.data, self.map_size, self.channels, self.dtype = data, map_size, channels, dtype
+        self.kept_C, self.packed = kept_C, packed
 
 
 class PreparedVoxels:
@@ -273,6 +283,66 @@ def prep_img_maps(img_featuremaps, map_size=137, dtype="f32"):
         _check(lib.list_prep_img_maps(maps, B, map_size, md, out.data_ptr(),
                                       out.numel() * out.element_size(), _stream()), "list_prep_img_maps")
     return PreparedImage(out, map_size, Ct, md)
+
+
+def img_proj_default(precision):
+    """Whether inference forwards through the module API take prep_img_proj for `precision`.  Measured at BASELINE
+    config 2 (B = 8, N = 20 000, 224^2; DESIGN 4 "Round 4b"): bf16x3 3.50 -> 3.17 ms, bf16 2.97 -> 2.77 ms; fp16 has
+    the 2-D sample inside fc_0 already (k_fc0_fused) and gains nothing.  LIST_IMG_PROJ=0 / 1 forces it off / on."""
+    e = os.environ.get("LIST_IMG_PROJ", "")
+    if e in ("0", "1"):
+        return e == "1"
+    prec = PRECISIONS[precision] if isinstance(precision, str) else int(precision)
+    return prec != PREC_FP16
+
+
+def img_proj_kept_levels(img_featuremaps, map_size=137):
+    """How many leading encoder levels prep_img_proj resizes (the rest is projected at its own resolution): a level is
+    projected when the resize enlarges it at least 2 x 2 (its H * W * 4 <= map_size^2) and so is every level behind it."""
+    n = len(img_featuremaps)
+    while n > 0 and img_featuremaps[n - 1].shape[2] * img_featuremaps[n - 1].shape[3] * 4 <= map_size * map_size:
+        n -= 1
+    return n
+
+
+def prep_img_proj(img_featuremaps, packed, map_size=137, precision="bf16x3", n_kept_levels=None):
+    """list_prep_img_proj: the perceptual map of an INFERENCE forward with the low-resolution encoder levels projected
+    through their columns of fc_0 before the resize (F.interpolate and fc_0 are both linear and commute:
+    network/modules.py:26-35, 276).  -> PreparedImage for sdf_query(..., save_for_backward=False) with `packed`."""
+    lib = load()
+    prec = PRECISIONS[precision] if isinstance(precision, str) else int(precision)
+    if len(img_featuremaps) != N_IMG_LEVELS:
+        raise RuntimeError(f"expected {N_IMG_LEVELS} image feature maps, got {len(img_featuremaps)}")
+    if n_kept_levels is None:
+        n_kept_levels = img_proj_kept_levels(img_featuremaps, map_size)
+    if not 0 <= n_kept_levels < N_IMG_LEVELS:
+        raise ListError("prep_img_proj", ERR_UNSUPPORTED, "no encoder level is small enough to project")
+    maps = (ListMap2D * N_IMG_LEVELS)()
+    B = img_featuremaps[0].shape[0]
+    Ct = kept = 0
+    for i, t in enumerate(img_featuremaps):
+        _f32_cuda(t, f"img_featuremaps[{i}]")
+        if t.dim() != 4 or t.shape[0] != B:
+            raise RuntimeError(f"img_featuremaps[{i}] must be [B,C,H,W]")
+        maps[i] = ListMap2D(t.data_ptr(), t.shape[1], t.shape[2], t.shape[3], *t.stride())
+        Ct += t.shape[1]
+        kept += t.shape[1] if i < n_kept_levels else 0
+    if Ct != packed.img_C:
+        raise RuntimeError(f"the encoder levels hold {Ct} channels, the packed weights expect {packed.img_C}")
+    nbytes = lib.list_img_proj_map_bytes(maps, B, map_size, n_kept_levels, packed.H1, prec)
+    sbytes = lib.list_img_proj_scratch_bytes(maps, B, n_kept_levels, packed.H1, prec)
+    if nbytes == 0 or sbytes == 0:
+        raise ListError("list_img_proj_map_bytes", ERR_UNSUPPORTED, lib.list_last_error().decode("utf-8", "replace"))
+    dev = img_featuremaps[0].device
+    f16 = prec == PREC_FP16
+    out = torch.empty((B, map_size, map_size, kept + packed.H1), dtype=torch.float16 if f16 else torch.float32, device=dev)
+    scratch = torch.empty((sbytes,), dtype=torch.uint8, device=dev)
+    vc = (C.c_int32 * N_VOX_LEVELS)(*[int(c) for c in packed.vox_C])
+    with torch.cuda.device(dev):
+        _check(lib.list_prep_img_proj(maps, B, map_size, n_kept_levels, vc, packed.data.data_ptr(), packed.H1, packed.H2,
+                                      packed.H3, prec, out.data_ptr(), out.numel() * out.element_size(),
+                                      scratch.data_ptr(), sbytes, _stream()), "list_prep_img_proj")
+    return PreparedImage(out, map_size, Ct, MAP_F16 if f16 else MAP_F32, kept_C=kept, packed=packed)
 
 
 def prep_vox_maps(vox_feat, dtype="f32"):
@@ -444,6 +514,10 @@ def _fill_query_args(query, perm, scale, vox, packed, precision, trans_mat=None,
         a.img_dtype = img.dtype
         a.map_size, a.img_C = img.map_size, img.channels
         a.clamp_hi = float(clamp_hi)
+        if img.kept_C is not None:            # prep_img_proj's map: sampled channels | projected channels
+            if img.packed is not packed:
+                raise RuntimeError("the projected perceptual map was made for other packed weights")
+            a.img_proj, a.img_kept_C = 1, int(img.kept_C)
         keep += [tm, img]
     for i in range(N_VOX_LEVELS):
         a.vox[i] = vox.levels[i]
@@ -514,6 +588,8 @@ def sdf_query(query, trans_mat, img, vox, packed, perm=(2, 1, 0), scale=2.0, pre
     # nothing is kept for a backward: fc_1 / fc_2 / fc_out run as one kernel (fp16 operands), H2 stays in registers
     a.no_activations = int(keeps_no_activations(save_for_backward))
     a.no_fused_fc0 = 0 if fused_fc0 else 1            # (A/B runs: the 2-D gather kernel + k_gemm_nt_pp instead of k_fc0_fused)
+    if a.img_proj and (save_for_backward or not a.no_activations or percep_proj is not None):
+        raise RuntimeError("a map of prep_img_proj serves inference forwards only (no backward, no percep_proj)")
     if percep_proj is not None:
         if save_for_backward or percep_feat is not None:
             raise RuntimeError("percep_proj is an inference path: no backward, no pre-pooled features")
@@ -535,7 +611,7 @@ def sdf_query(query, trans_mat, img, vox, packed, perm=(2, 1, 0), scale=2.0, pre
         pl = ListQueryPlan()
         _check(lib.list_query_plan(C.byref(a), C.byref(pl)), "list_query_plan")
         plan.update(chunks=pl.chunks, rows_per_chunk=pl.rows_per_chunk, fused_tail=pl.fused_tail, fc0_k=pl.fc0_k,
-                    box_levels=pl.box_levels, fused_fc0=pl.fused_fc0)
+                    box_levels=pl.box_levels, fused_fc0=pl.fused_fc0, img_proj=pl.img_proj)
     with torch.cuda.device(query.device):
         _check(lib.list_sdf_query_fwd(C.byref(a), _stream()), "list_sdf_query_fwd")
     if save_for_backward:

@@ -205,15 +205,10 @@ def sdf_query(query, trans_mat, img_maps, vox_maps, mlp_params, *, perm=(2, 1, 0
     vox_maps = [v if (v.dtype == torch.float16 and v.shape[1] > 1) else _f32(v) for v in vox_maps]
     mlp = [mlp_params[k] for k in MLP_KEYS]
     md = hip.map_dtype_for(precision)
-    if percep_feat is None:
-        img_maps = [_f32(m) for m in img_maps]
-        img = caches.setdefault("img:" + md, _Cache()).get(
-            img_maps, lambda: hip.prep_img_maps([m.detach() for m in img_maps], map_size, md))
-    else:
-        img_maps, img = [], None
+    img_maps = [_f32(m) for m in img_maps] if percep_feat is None else []
     vox = caches.setdefault("vox:" + md, _Cache()).get(
         vox_maps, lambda: hip.prep_vox_maps([v.detach() for v in vox_maps], md))
-    img_C = img.channels if img is not None else percep_feat.shape[1]
+    img_C = sum(m.shape[1] for m in img_maps) if percep_feat is None else percep_feat.shape[1]
     mlp_dict = {k: t.detach() for k, t in zip(MLP_KEYS, mlp)}
     training = torch.is_grad_enabled() and any(t.requires_grad for t in mlp)
     if training:          # parameters move every step (and `.data` writes are invisible to a cache): pack afresh
@@ -221,13 +216,33 @@ def sdf_query(query, trans_mat, img_maps, vox_maps, mlp_params, *, perm=(2, 1, 0
     else:
         packed = caches.setdefault("mlp:" + str(precision), _Cache()).get(
             mlp, lambda: hip.prep_mlp_weights(mlp_dict, vox.channels, img_C, precision))
+    diff = [t for t in (trans_mat, percep_feat, *img_maps, *vox_maps, *mlp)
+            if t is not None and t.requires_grad]
+    inference = not (torch.is_grad_enabled() and diff)
+    # many points per image on fixed maps and weights (an inference grid): the perceptual block of fc_0 is applied
+    # to the 137^2 map once (hip.prep_percep_proj, cached with the map and the weights) instead of per point
+    want = project_percep if project_percep is not None else (
+        ordered_points and percep_feat is None and query.shape[1] >= 4 * map_size * map_size)
+    img = None
+    if percep_feat is None and inference and not want and hip.img_proj_default(precision) \
+            and hip.img_proj_kept_levels(img_maps, map_size) < N_IMG:
+        # inference forwards: the low-resolution encoder levels (896 of the 1024 perceptual channels) go through their
+        # columns of fc_0 BEFORE the resize, 14^2 .. 56^2 pixels per image instead of one product per query point
+        # (hip.prep_img_proj, list_prep_img_proj: F.interpolate and fc_0 are linear and commute)
+        def make_proj():
+            try:
+                return hip.prep_img_proj([m.detach() for m in img_maps], packed, map_size, precision)
+            except hip.ListError as e:             # channel counts the projection does not take
+                if e.code == hip.ERR_UNSUPPORTED:
+                    return False
+                raise
+        img = caches.setdefault("imgproj:" + str(precision), _Cache()).get(img_maps + [packed.data], make_proj) or None
+    if percep_feat is None and img is None:
+        img = caches.setdefault("img:" + md, _Cache()).get(
+            img_maps, lambda: hip.prep_img_maps([m.detach() for m in img_maps], map_size, md))
 
     def run():
         proj = None
-        # many points per image on fixed maps and weights (an inference grid): the perceptual block of fc_0 is applied
-        # to the 137^2 map once (hip.prep_percep_proj, cached with the map and the weights) instead of per point
-        want = project_percep if project_percep is not None else (
-            ordered_points and img is not None and query.shape[1] >= 4 * img.map_size * img.map_size)
         if want and img is not None and not training and not torch.is_grad_enabled():
             def make():
                 try:
@@ -242,8 +257,6 @@ def sdf_query(query, trans_mat, img_maps, vox_maps, mlp_params, *, perm=(2, 1, 0
                              percep_feat=percep_feat.detach() if percep_feat is not None else None,
                              sort_points=not ordered_points, percep_proj=proj)
 
-    diff = [t for t in (trans_mat, percep_feat, *img_maps, *vox_maps, *mlp)
-            if t is not None and t.requires_grad]
     if torch.is_grad_enabled() and diff and query.shape[0] * query.shape[1] > 0:
         q_det = query.detach()
         tm_det = trans_mat.detach() if trans_mat is not None else None

@@ -117,6 +117,47 @@ int main() {
   e = a; e.percep_proj = fake(0xB000000); e.img_dtype = LIST_MAP_F32;        // fp16 operands with an fp32 map
   EXPECT(list_sdf_query_fwd(&e, NULL) == LIST_ERR_UNSUPPORTED);
 
+  // ---- projected encoder levels (ABI 8): the flag's contract, before any launch
+  e = a; e.img_proj = 1; e.img_kept_C = 128; e.no_activations = 0;           // a forward a backward may follow
+  EXPECT(list_sdf_query_fwd(&e, NULL) == LIST_ERR_ARG);
+  e = a; e.img_proj = 2;
+  EXPECT(list_sdf_query_fwd(&e, NULL) == LIST_ERR_ARG);
+  e = a; e.img_kept_C = 128;                                                  // kept channels without the flag
+  EXPECT(list_sdf_query_fwd(&e, NULL) == LIST_ERR_ARG);
+  e = a; e.img_proj = 1; e.img_kept_C = 100;
+  EXPECT(list_sdf_query_fwd(&e, NULL) == LIST_ERR_UNSUPPORTED);
+  e = a; e.img_proj = 1; e.img_kept_C = 1024;                                 // nothing left to project
+  EXPECT(list_sdf_query_fwd(&e, NULL) == LIST_ERR_UNSUPPORTED);
+  e = a; e.img_proj = 1; e.img_kept_C = 128; e.percep_proj = fake(0xB000000);
+  EXPECT(list_sdf_query_fwd(&e, NULL) == LIST_ERR_ARG);
+  e = a; e.img_proj = 1; e.img_kept_C = 128; e.img_dtype = LIST_MAP_F32;      // fp16 operands with an fp32 map
+  EXPECT(list_sdf_query_fwd(&e, NULL) == LIST_ERR_UNSUPPORTED);
+  {
+    ListMap2D lv[LIST_N_IMG_LEVELS];
+    const int cs[5] = {64, 64, 128, 256, 512}, rs[5] = {224, 112, 56, 28, 14};
+    for (int i = 0; i < 5; ++i) {
+      lv[i].data = (const float*)fake(0x60000000); lv[i].C = cs[i]; lv[i].H = lv[i].W = rs[i];
+      lv[i].sb = (int64_t)cs[i] * rs[i] * rs[i]; lv[i].sc = (int64_t)rs[i] * rs[i]; lv[i].sh = rs[i]; lv[i].sw = 1;
+    }
+    EXPECT(list_img_proj_map_bytes(lv, 8, 137, 2, 512, LIST_PREC_FP16) == (size_t)8 * 137 * 137 * 640 * 2);
+    EXPECT(list_img_proj_map_bytes(lv, 8, 137, 5, 512, LIST_PREC_FP16) == 0);
+    EXPECT(list_img_proj_map_bytes(lv, 8, 137, -1, 512, LIST_PREC_FP16) == 0);
+    EXPECT(list_img_proj_map_bytes(lv, 0, 137, 2, 512, LIST_PREC_FP16) == 0);
+    EXPECT(list_img_proj_map_bytes(lv, 8, 137, 2, 500, LIST_PREC_FP16) == 0);
+    EXPECT(list_img_proj_scratch_bytes(lv, 8, 2, 512, 7) == 0);
+    const size_t sb = list_img_proj_scratch_bytes(lv, 8, 2, 512, LIST_PREC_BF16X3);
+    EXPECT(sb > 0);
+    const int32_t vc[LIST_N_VOX_LEVELS] = {1, 16, 32, 64, 128, 128};
+    // refused before any launch: NULL buffers, a short output, a short scratch, a misaligned scratch
+    EXPECT(list_prep_img_proj(lv, 8, 137, 2, vc, fake(0x9000000), 512, 256, 256, LIST_PREC_BF16X3, NULL, 0, fake(0x70000000), sb, NULL) == LIST_ERR_ARG);
+    EXPECT(list_prep_img_proj(lv, 8, 137, 2, vc, fake(0x9000000), 512, 256, 256, LIST_PREC_BF16X3, fake(0x80000000), 1000, fake(0x70000000), sb, NULL) == LIST_ERR_WORKSPACE);
+    EXPECT(list_prep_img_proj(lv, 8, 137, 2, vc, fake(0x9000000), 512, 256, 256, LIST_PREC_BF16X3, fake(0x80000000), (size_t)1 << 40, fake(0x70000000), sb - 1, NULL) == LIST_ERR_WORKSPACE);
+    EXPECT(list_prep_img_proj(lv, 8, 137, 2, vc, fake(0x9000000), 512, 256, 256, LIST_PREC_BF16X3, fake(0x80000000), (size_t)1 << 40, fake(0x70000008), sb, NULL) == LIST_ERR_SHAPE);
+    EXPECT(list_prep_img_proj(lv, 8, 400, 2, vc, fake(0x9000000), 512, 256, 256, LIST_PREC_BF16X3, fake(0x80000000), (size_t)1 << 40, fake(0x70000000), sb, NULL) == LIST_ERR_SHAPE);
+    lv[4].C = 500;
+    EXPECT(list_prep_img_proj(lv, 8, 137, 2, vc, fake(0x9000000), 512, 256, 256, LIST_PREC_BF16X3, fake(0x80000000), (size_t)1 << 40, fake(0x70000000), sb, NULL) == LIST_ERR_UNSUPPORTED);
+  }
+
   // ---- the plan: what the library would dispatch, from the same validation (no launch)
   ListQueryPlan pl;
   EXPECT(list_query_plan(&a, NULL) == LIST_ERR_ARG);
@@ -124,8 +165,11 @@ int main() {
   EXPECT(list_query_plan(&a, &pl) == LIST_OK && pl.chunks == 1 && pl.rows_per_chunk == 160000 && pl.fused_tail == 1 &&
          pl.fc0_k == 3648 && pl.box_levels == ((1 << 4) | (1 << 5)));
   EXPECT(pl.fused_fc0 == 1);                                                  // inference forward, fp16 operands and maps
+  EXPECT(pl.img_proj == 0);
   e = a; e.no_fused_fc0 = 1;
   EXPECT(list_query_plan(&e, &pl) == LIST_OK && pl.fused_fc0 == 0 && pl.fused_tail == 1);
+  e = a; e.img_proj = 1; e.img_kept_C = 128;                                  // fc_0 without the projected levels' 896 columns
+  EXPECT(list_query_plan(&e, &pl) == LIST_OK && pl.img_proj == 1 && pl.fc0_k == 3648 - 896 && pl.fused_fc0 == 0);
   e = a; e.no_activations = 0;
   EXPECT(list_query_plan(&e, &pl) == LIST_OK && pl.fused_tail == 0 && pl.fused_fc0 == 0);
   e = a; e.precision = LIST_PREC_BF16X3;

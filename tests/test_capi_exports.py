@@ -36,10 +36,10 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_error_string_without_gpu():
     from list_amd import hip
     lib = hip.load()
-    assert lib.list_abi_version() == 7
+    assert lib.list_abi_version() == 8
     text = open(os.path.join(ROOT, "include", "list_hip.h")).read()
-    assert "#define LIST_ABI_VERSION 7" in text
-    assert hip.ABI_VERSION == 7                      # header, library and ctypes structs move together
+    assert "#define LIST_ABI_VERSION 8" in text
+    assert hip.ABI_VERSION == 8                      # header, library and ctypes structs move together
     # argument validation happens before any HIP call: a NULL args struct is rejected cleanly
     assert lib.list_sdf_query_fwd(None, None) == -1
     assert b"NULL" in lib.list_last_error()
@@ -55,6 +55,24 @@ def test_abi_version_and_error_string_without_gpu():
     assert lib.list_percep_proj_bytes(1, 137, 512, 0) == 18944 * 512 * 4
     assert lib.list_percep_proj_scratch_bytes(1, 137, 1024, 2) == 0
     assert lib.list_percep_proj_scratch_bytes(1, 137, 1024, 0) == 18769 * 1024 * 4
+    # projected encoder levels (ABI 8), host arithmetic only: the map is [B][137][137][kept_C + H1]; two kept levels of the
+    # 224^2 pyramid = 128 sampled channels; a level count that leaves nothing to project, or a channel count that is
+    # not a multiple of 64, is refused with a message
+    maps = (hip.ListMap2D * hip.N_IMG_LEVELS)()
+    keep = ctypes.create_string_buffer(64)
+    for i, (c, r) in enumerate(zip((64, 64, 128, 256, 512), (224, 112, 56, 28, 14))):
+        maps[i] = hip.ListMap2D(ctypes.addressof(keep), c, r, r, c * r * r, r * r, r, 1)
+    assert lib.list_img_proj_map_bytes(maps, 8, 137, 2, 512, 2) == 8 * 137 * 137 * (128 + 512) * 2
+    assert lib.list_img_proj_map_bytes(maps, 8, 137, 2, 512, 0) == 8 * 137 * 137 * (128 + 512) * 4
+    assert lib.list_img_proj_map_bytes(maps, 8, 137, 0, 512, 0) == 8 * 137 * 137 * 512 * 4
+    fp16_scratch = lib.list_img_proj_scratch_bytes(maps, 8, 2, 512, 2)
+    rows = [8 * r * r for r in (56, 28, 14)]
+    pad = [(x + 255) // 256 * 256 for x in rows]
+    assert fp16_scratch == sum(x * c * 2 + p * 512 * 4 for x, p, c in zip(rows, pad, (128, 256, 512)))
+    assert lib.list_img_proj_scratch_bytes(maps, 8, 2, 512, 0) > fp16_scratch
+    assert lib.list_img_proj_map_bytes(maps, 8, 137, 5, 512, 0) == 0 and b"n_kept_levels" in lib.list_last_error()
+    maps[3].C = 200
+    assert lib.list_img_proj_scratch_bytes(maps, 8, 2, 512, 0) == 0 and b"multiples of 64" in lib.list_last_error()
 
 
 def test_missing_library_fails_loudly(monkeypatch):
@@ -74,7 +92,7 @@ def test_binding_refuses_a_library_of_another_abi_version(monkeypatch):
     hip.load()                                       # the real pair agrees
     monkeypatch.setattr(hip, "_lib", None)           # force a fresh load against a binding that claims another version
     monkeypatch.setattr(hip, "ABI_VERSION", hip.ABI_VERSION - 1)
-    with pytest.raises(RuntimeError, match="speaks ABI 7, this binding ABI 6"):
+    with pytest.raises(RuntimeError, match="speaks ABI 8, this binding ABI 7"):
         hip.load()
     assert hip._lib is None                          # nothing half-loaded is left behind
 

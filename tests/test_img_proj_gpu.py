@@ -1,0 +1,215 @@
+"""GPU: inference forwards with the low-resolution encoder levels projected through their columns of fc_0 BEFORE the
+resize (list_prep_img_proj + ListQueryArgs.img_proj, ABI 8).  F.interpolate (network/modules.py:26-35) and fc_0
+(network/modules.py:276) are linear, so  fc_0-columns(resize(x_l)) == resize(fc_0-columns(x_l)): same field, other
+rounding.  Checked against the numpy oracle (explicit formulas of the reference) at the mode's bound, against the
+reference's own goldens, against the standard path (tight), at BASELINE configs 2 and 5 in full size, with every
+number of kept levels, plus the size-independent properties (point permutation, batch shard, unsorted points: bit
+for bit within the path) and the argument contract."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases, list_oracle as O
+from test_baseline_configs_gpu import make_inputs, oracle_subset
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+# absolute bound per mode at |sdf| <= 0.1 (the synthetic weights' range): north_star's 1e-4 for the fp32-grade and the
+# fp16 mode, the stated 5e-3 for plain bf16
+BOUND = {"bf16x3": 1e-4, "fp16": 1e-4, "bf16": 5e-3}
+# against the standard path of the same mode: rounding of one more fp32 -> operand-format conversion per projected level
+CLOSE = {"bf16x3": 5e-6, "fp16": 1.5e-4, "bf16": 2e-3}
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import __graft_entry__ as ge
+    ge.build()
+    from list_amd import hip as h
+    h.load()
+    return h
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def run_proj(hip, inp, precision, query=None, n_kept=None, plan=None, sort=True, T=None):
+    md = hip.map_dtype_for(precision)
+    vox = hip.prep_vox_maps(inp["vox"], md)
+    packed = hip.prep_mlp_weights(inp["w"], vox.channels, sum(m.shape[1] for m in inp["img"]), precision)
+    img = hip.prep_img_proj(inp["img"], packed, inp["map_size"], precision, n_kept_levels=n_kept)
+    q = inp["query"] if query is None else query
+    return hip.sdf_query(q, inp["T"] if T is None else T, img, vox, packed, precision=precision, clamp_hi=inp["clamp_hi"],
+                         plan=plan, sort_points=sort)
+
+
+def run_std(hip, inp, precision):
+    md = hip.map_dtype_for(precision)
+    img = hip.prep_img_maps(inp["img"], inp["map_size"], md)
+    vox = hip.prep_vox_maps(inp["vox"], md)
+    packed = hip.prep_mlp_weights(inp["w"], vox.channels, img.channels, precision)
+    return hip.sdf_query(inp["query"], inp["T"], img, vox, packed, precision=precision, clamp_hi=inp["clamp_hi"])
+
+
+def case_inputs(name):
+    c = cases.build_case(name)
+    return dict(img=[dev(m) for m in c["img_maps"]], vox=[dev(m) for m in c["vox_maps"]], query=dev(c["query"]),
+                T=dev(c["trans_mat"]), w={k: dev(v) for k, v in c["weights"].items()}, map_size=137, clamp_hi=136.0), c
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16", "bf16"])
+def test_golden_cases_against_the_oracle_and_the_standard_path(hip, precision):
+    for name in ("tiny", "small", "real", "edge"):
+        inp, c = case_inputs(name)
+        ref = O.list_query(c["query"], c["img_maps"], c["vox_maps"], c["trans_mat"], c["weights"])
+        plan = {}
+        got = run_proj(hip, inp, precision, plan=plan).cpu().numpy()
+        assert plan["img_proj"] == 1 and plan["fused_fc0"] == 0
+        kept = hip.img_proj_kept_levels(inp["img"], 137)
+        kept_C = sum(m.shape[1] for m in inp["img"][:kept])
+        assert plan["fc0_k"] == 3648 - (1024 - kept_C)
+        err = float(np.abs(got - ref).max())
+        close = float(np.abs(got - run_std(hip, inp, precision).cpu().numpy()).max())
+        print(f"{name} {precision}: kept levels {kept}, |err| vs oracle {err:.3e}, vs the standard path {close:.3e}")
+        assert err < BOUND[precision], (name, err)
+        assert close < CLOSE[precision], (name, close)
+
+
+def test_the_reference_goldens(hip):
+    """tests/golden/hotpath_*.npz: SDF the reference's own modules produced for these inputs (oracle/gen_golden.py)."""
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    n = 0
+    for name in ("tiny", "small", "real", "edge"):
+        f = os.path.join(gold, f"hotpath_{name}.npz")
+        if not os.path.exists(f):
+            continue
+        g = np.load(f)
+        inp, _ = case_inputs(name)
+        got = run_proj(hip, inp, "bf16x3").cpu().numpy()
+        assert float(np.abs(got - g["sdf"].reshape(got.shape)).max()) < 1e-4, name
+        n += 1
+    assert n >= 2
+
+
+def test_every_number_of_kept_levels(hip):
+    inp, c = case_inputs("real")
+    ref = O.list_query(c["query"], c["img_maps"], c["vox_maps"], c["trans_mat"], c["weights"])
+    for k in range(0, 5):
+        plan = {}
+        got = run_proj(hip, inp, "bf16x3", n_kept=k, plan=plan).cpu().numpy()
+        kept_C = sum(m.shape[1] for m in inp["img"][:k])
+        assert plan["fc0_k"] == 3648 - (1024 - kept_C)
+        assert float(np.abs(got - ref).max()) < 1e-5, k
+    with pytest.raises(hip.ListError):
+        run_proj(hip, inp, "bf16x3", n_kept=5)
+
+
+@pytest.mark.parametrize("precision", ["fp16", "bf16x3"])
+def test_config2_full_size(hip, precision):
+    inp = make_inputs(8, 20000, 224, 128, 137)
+    sdf = run_proj(hip, inp, precision)
+    assert torch.isfinite(sdf).all()
+    err, scale = oracle_subset(inp, sdf, 256, seed=11)
+    print(f"config 2 img_proj {precision}: max-abs err {err:.3e} over 8 x 256 points (|sdf| <= {scale:.3f})")
+    assert err < 1e-4, err
+    # size-independent properties, bit for bit within the path: point permutation, unsorted points, a batch shard
+    perm = torch.from_numpy(np.random.RandomState(0).permutation(20000)).to(DEV)
+    assert torch.equal(run_proj(hip, inp, precision, inp["query"][:, perm].contiguous()), sdf[:, perm])
+    assert torch.equal(run_proj(hip, inp, precision, sort=False), sdf)
+    one = dict(inp, img=[m[5:6] for m in inp["img"]], vox=[m[5:6] for m in inp["vox"]], T=inp["T"][5:6],
+               query=inp["query"][5:6])
+    assert torch.equal(run_proj(hip, one, precision)[0], sdf[5])
+
+
+def test_config5_full_size_bf16x3(hip):
+    inp = make_inputs(8, 50000, 512, 128, 274, seed=555)
+    assert hip.img_proj_kept_levels(inp["img"], 274) == 2
+    sdf = run_proj(hip, inp, "bf16x3")
+    err, _ = oracle_subset(inp, sdf, 256, seed=12)
+    print(f"config 5 img_proj bf16x3: max-abs err {err:.3e}")
+    assert err < 1e-4, err
+    half = 25000
+    pieces = torch.cat([run_proj(hip, inp, "bf16x3", inp["query"][:, :half]), run_proj(hip, inp, "bf16x3", inp["query"][:, half:])], 1)
+    assert torch.equal(pieces, sdf)
+
+
+def test_points_on_and_beyond_the_clamp_and_nan_coordinates(hip):
+    """Projections piled onto the clamp of network/modules.py:43 (an untrained spatial transformer), beyond the map and
+    NaN coordinates: the projected sample masks its out-of-map taps like the reference; NaN points give NaN."""
+    inp, c = case_inputs("small")
+    T = inp["T"].clone()
+    T[:, :3, :2] *= 8.0
+    cw = dict(c, trans_mat=T.cpu().numpy())
+    ref = O.list_query(cw["query"], cw["img_maps"], cw["vox_maps"], cw["trans_mat"], cw["weights"])
+    got = run_proj(hip, inp, "bf16x3", T=T).cpu().numpy()
+    assert float(np.abs(got - ref).max()) < 1e-4
+    q = inp["query"].clone()
+    q[0, 3, 1] = float("nan")
+    got = run_proj(hip, inp, "bf16x3", query=q).cpu().numpy()
+    base = run_proj(hip, inp, "bf16x3").cpu().numpy()
+    assert np.isnan(got[0, 3]) and np.isnan(got).sum() == 1
+    mask = np.ones_like(got, bool)
+    mask[0, 3] = False
+    # (the NaN point's 256-row tile is redone with the reference's skip semantics, gather_kernels.hip k_gather_fixup: its
+    # coarse levels then come from the per-sample form instead of the shared-tap one -- last-bit differences, as on the
+    # standard path)
+    assert float(np.abs(got[mask] - base[mask]).max()) < 1e-6
+
+
+def test_module_api_takes_the_projection_for_inference_only(hip, monkeypatch):
+    """network/hotpath.sdf_query: inference forwards in the bf16 formats take the projected map (hip.img_proj_default),
+    a forward that a backward may follow never does; LIST_IMG_PROJ=0 / 1 forces it."""
+    from list_amd.network import hotpath
+    inp, c = case_inputs("small")
+    seen = []
+    real = hip.sdf_query
+
+    def spy(*a, **k):
+        seen.append(a[2].kept_C)
+        return real(*a, **k)
+    monkeypatch.setattr(hip, "sdf_query", spy)
+    mlp = {k: v.clone() for k, v in inp["w"].items()}
+    with torch.no_grad():
+        a = hotpath.sdf_query(inp["query"], inp["T"], inp["img"], inp["vox"], mlp, precision="bf16x3", caches={})
+    assert seen[-1] is not None
+    monkeypatch.setenv("LIST_IMG_PROJ", "0")
+    with torch.no_grad():
+        b = hotpath.sdf_query(inp["query"], inp["T"], inp["img"], inp["vox"], mlp, precision="bf16x3", caches={})
+    assert seen[-1] is None
+    assert float((a - b).abs().max()) < 5e-6
+    monkeypatch.setenv("LIST_IMG_PROJ", "1")
+    for v in mlp.values():
+        v.requires_grad_(True)
+    s = hotpath.sdf_query(inp["query"], inp["T"], inp["img"], inp["vox"], mlp, precision="bf16x3", caches={})
+    assert seen[-1] is None and s.requires_grad
+    s.sum().backward()
+    assert all(v.grad is not None for v in mlp.values())
+
+
+def test_argument_contract(hip):
+    inp, _ = case_inputs("tiny")
+    md = hip.map_dtype_for("bf16x3")
+    vox = hip.prep_vox_maps(inp["vox"], md)
+    packed = hip.prep_mlp_weights(inp["w"], vox.channels, 1024, "bf16x3")
+    img = hip.prep_img_proj(inp["img"], packed, 137, "bf16x3")
+    with pytest.raises(RuntimeError, match="inference"):
+        hip.sdf_query(inp["query"], inp["T"], img, vox, packed, precision="bf16x3", save_for_backward=True)
+    other = hip.prep_mlp_weights(inp["w"], vox.channels, 1024, "bf16x3")
+    with pytest.raises(RuntimeError, match="other packed weights"):
+        hip.sdf_query(inp["query"], inp["T"], img, vox, other, precision="bf16x3")
+    # the C side: a projected map with operands of the other class, img_kept_C without img_proj
+    a, keep = hip._fill_query_args(inp["query"], (2, 1, 0), 2.0, vox, packed, "bf16x3", inp["T"], img)
+    a.no_activations = 0
+    pl = hip.ListQueryPlan()
+    lib = hip.load()
+    assert lib.list_query_plan(C.byref(a), C.byref(pl)) == hip.ERR_ARG and b"no_activations" in lib.list_last_error()
+    a.no_activations, a.img_proj = 1, 0
+    assert lib.list_query_plan(C.byref(a), C.byref(pl)) == hip.ERR_ARG and b"img_kept_C" in lib.list_last_error()
+    a.img_proj, a.img_kept_C = 1, 96
+    assert lib.list_query_plan(C.byref(a), C.byref(pl)) == hip.ERR_UNSUPPORTED
+    a.img_kept_C = int(img.kept_C)
+    assert lib.list_query_plan(C.byref(a), C.byref(pl)) == 0 and pl.img_proj == 1
