@@ -156,11 +156,19 @@ def kernel_table(B, N, img_res, vox_res, map_size, x_bytes_per_feature, map_byte
 FORCE_EXCHANGE = os.environ.get("LIST_BENCH_FORCE_EXCHANGE", "0") == "1"
 
 
-def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gather_fn, sustained_steps=0, fused_fc0=True):
+def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gather_fn, sustained_steps=0, fused_fc0=True,
+               img_proj=None):
     import torch
     import torch.distributed as dist
     multi = world > 1 or FORCE_EXCHANGE
     B, N = inp["B"], inp["N"]
+    # img_proj (list_prep_img_proj, ABI 8): the low-resolution encoder levels go through their columns of fc_0 BEFORE the
+    # resize (inside the timed step, in place of list_prep_img_maps).  None = what the module API does for an inference
+    # forward in this precision (hip.img_proj_default: the bf16 formats; fp16 keeps the 2-D sample inside fc_0)
+    if img_proj is None:
+        img_proj = hip.img_proj_default(precision)
+    img_proj = bool(img_proj) and not inp.get("ordered_points") and \
+        hip.img_proj_kept_levels(inp["img_maps"], inp["map_size"]) < hip.N_IMG_LEVELS
     n_ev = hip.N_STAGES
     # one event set per row chunk of the call (ListQueryArgs.stage_event_sets): the intervals of all chunks are
     # summed, so kernel_ms is the time of ALL launches of a kernel in one step
@@ -201,11 +209,20 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
             pending[k] = None
         if pre: ev.record(pre[0])
         md = hip.map_dtype_for(precision)
-        img = hip.prep_img_maps(inp["img_maps"], inp["map_size"], md)
-        if pre: ev.record(pre[1])
-        vox = hip.prep_vox_maps(inp["vox_maps"], md)
-        if pre: ev.record(pre[2])
-        packed = hip.prep_mlp_weights(inp["weights"], vox.channels, img.channels, precision)
+        if img_proj:
+            # the projection needs the packed weights: hand-off of the voxel levels, weight repack, then the 2-D side
+            # (intervals [0,1] = voxel hand-off, [1,2] = weights, [2,3] = resize + projection; renamed below)
+            vox = hip.prep_vox_maps(inp["vox_maps"], md)
+            if pre: ev.record(pre[1])
+            packed = hip.prep_mlp_weights(inp["weights"], vox.channels, sum(m.shape[1] for m in inp["img_maps"]), precision)
+            if pre: ev.record(pre[2])
+            img = hip.prep_img_proj(inp["img_maps"], packed, inp["map_size"], precision)
+        else:
+            img = hip.prep_img_maps(inp["img_maps"], inp["map_size"], md)
+            if pre: ev.record(pre[1])
+            vox = hip.prep_vox_maps(inp["vox_maps"], md)
+            if pre: ev.record(pre[2])
+            packed = hip.prep_mlp_weights(inp["weights"], vox.channels, img.channels, precision)
         # inference grid (executors.LIST.predict_grid): many points on one image -- the perceptual block of fc_0 is
         # applied to the 137^2 map once (inside the timed step, counted with prep_weights) and sampled per point
         proj = hip.prep_percep_proj(img, packed, precision) if inp.get("ordered_points") else None
@@ -265,9 +282,10 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
     def interval(arr, c, s0, s1):
         return ev.elapsed_ms(ctypes.c_void_p(arr[c * n_ev + s0]), ctypes.c_void_p(arr[c * n_ev + s1]))
     for pre, arr in step_events:
-        acc[0] += ev.elapsed_ms(pre[0], pre[1])
-        acc[1] += ev.elapsed_ms(pre[1], pre[2])
-        acc[2] += ev.elapsed_ms(pre[2], pre[3])
+        i_img, i_vox, i_w = (2, 0, 1) if img_proj else (0, 1, 2)          # which interval holds which prep (see step())
+        acc[0] += ev.elapsed_ms(pre[i_img], pre[i_img + 1])
+        acc[1] += ev.elapsed_ms(pre[i_vox], pre[i_vox + 1])
+        acc[2] += ev.elapsed_ms(pre[i_w], pre[i_w + 1])
         for c in range(n_chunks):
             group += interval(arr, c, first, hip.STAGE_IMG + 1)
             for s in range(n_ev - 1):
@@ -287,6 +305,9 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
         kernel_ms["fc_2_out"] += kernel_ms["fc_1"]
         kernel_ms["fc_1"] = 0.0
         kernel_ms["_fused_tail"] = 1
+    assert bool(plan.get("img_proj")) == img_proj, (plan, img_proj)
+    if img_proj:
+        kernel_ms["_img_proj"] = 1          # prep_img_resize_nhwc = resize of the kept levels + projections + their resized sum
     if plan.get("fused_fc0"):
         # fc_0 produced the perceptual block of its A operand on chip (k_fc0_fused): no 2-D gather kernel ran
         kernel_ms["_fused_fc0"] = 1
@@ -772,6 +793,26 @@ def main():
                     "roofline_frac": P_FLOP_FC0(B * N) / (b_ms["fc_0"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                     "max_abs_diff_vs_headline": float((b_sdf - sdf).abs().max())}
 
+    alt_img_proj = None
+    if args.precision is None and not grid and alt is not None:
+        # list_prep_img_proj (ABI 8) on / off beside what the modes above ran: the fp16 headline with it forced on (the
+        # 2-D sample then leaves fc_0 again: k_gather_img + k_gemm_nt_pp with a row-vector epilogue), the bf16x3 mode
+        # with it forced off (the round-3 path)
+        p_steps = max(2, args.steps // 2)
+        on_el, on_ms, on_sdf, _ = run_config(args, headline, p_steps, min(args.warmup, 2), inp, hip, ev, world, device,
+                                             gather_fn, img_proj=not kernel_ms.get("_img_proj"))
+        off_el, off_ms, off_sdf, _ = run_config(args, alt_prec, p_steps, min(args.warmup, 2), inp, hip, ev, world, device,
+                                                gather_fn, img_proj=not alt["kernel_ms"].get("_img_proj"))
+        alt_img_proj = {
+            "what": "low-resolution encoder levels projected through fc_0 before the resize (list_prep_img_proj): "
+                    "default for the bf16 formats, off for fp16 (hip.img_proj_default)",
+            headline: {"img_proj": bool(on_ms.get("_img_proj")), "ms_per_step": on_el / p_steps * 1e3, "fc_0_ms": on_ms["fc_0"],
+                       "prep_img_ms": on_ms["prep_img_resize_nhwc"], "gathers_ms": on_ms["gathers_back_to_back"],
+                       "max_abs_diff_vs_mode": float((on_sdf - sdf).abs().max())},
+            alt_prec: {"img_proj": bool(off_ms.get("_img_proj")), "ms_per_step": off_el / p_steps * 1e3, "fc_0_ms": off_ms["fc_0"],
+                       "prep_img_ms": off_ms["prep_img_resize_nhwc"], "gathers_ms": off_ms["gathers_back_to_back"],
+                       "max_abs_diff_vs_mode": float((off_sdf - a_sdf).abs().max())}}
+
     train = None
     train_grads = None
     if args.precision is None and not args.no_train_step and B * N <= 262144:
@@ -907,9 +948,15 @@ def main():
             # arguments.py:54).  Stated tolerances: fp16 1e-3 x max|sdf|, bf16x3 1e-4 absolute; both asserted here.
             md_of = hip.map_dtype_for
             def forward(prec, weights):
-                img_p = hip.prep_img_maps(inp["img_maps"], inp["map_size"], md_of(prec))
+                # the path the mode is TIMED on (run_config): the bf16 formats project the low-resolution encoder levels
+                # through fc_0 before the resize (list_prep_img_proj), fp16 samples all 1024 channels inside fc_0
                 vox_p = hip.prep_vox_maps(inp["vox_maps"], md_of(prec))
-                pk = hip.prep_mlp_weights(weights, vox_p.channels, img_p.channels, prec)
+                pk = hip.prep_mlp_weights(weights, vox_p.channels, sum(m.shape[1] for m in inp["img_maps"]), prec)
+                if hip.img_proj_default(prec) and not inp.get("ordered_points") and \
+                        hip.img_proj_kept_levels(inp["img_maps"], inp["map_size"]) < hip.N_IMG_LEVELS:
+                    img_p = hip.prep_img_proj(inp["img_maps"], pk, inp["map_size"], prec)
+                else:
+                    img_p = hip.prep_img_maps(inp["img_maps"], inp["map_size"], md_of(prec))
                 pj = hip.prep_percep_proj(img_p, pk, prec) if inp.get("ordered_points") else None
                 o = hip.sdf_query(inp["query"], inp["trans_mat"], img_p, vox_p, pk, precision=prec,
                                   clamp_hi=inp["clamp_hi"], sort_points=not inp.get("ordered_points", False), percep_proj=pj)
@@ -1013,6 +1060,7 @@ def main():
         "alt": alt,
         "alt_bf16": alt_bf16,
         "alt_unfused_fc0": alt_unfused,
+        "alt_img_proj": alt_img_proj,
         "alt_channels_last_inputs": alt_cl,
         "train_step": train,
         "whole_model": whole,
@@ -1026,6 +1074,9 @@ def main():
         pv = m.get("parity_vs_cpu")
         errs = [float(f"{pv[k]['max_abs_err']:.1e}") for k in ("bench_distribution", "sdf_about_0.5")] if pv else None
         return {"Mpts": round(m["value"] / 1e6, 2), "ms": round(m["ms_per_step"], 3), "err": errs}
+    if alt is not None:
+        modes[alt["precision"]]["img_proj"] = bool(alt["kernel_ms"].get("_img_proj"))
+    modes[headline]["img_proj"] = bool(kernel_ms.get("_img_proj"))
     out["summary"] = {
         "fp16": _mode("fp16"), "bf16x3": _mode("bf16x3"), "bf16": _mode("bf16"),
         "channels_last_Mpts": round(alt_cl["value"] / 1e6, 2) if alt_cl else None,
@@ -1034,6 +1085,9 @@ def main():
         "fc0_ms": round(kernel_ms["fc_0"], 4), "fc0_frac": round(roof["frac"], 3),
         "unfused": [round(alt_unfused["ms_per_step"], 3), round(alt_unfused["fc_0_ms"], 4),
                     round(alt_unfused["fc_0_frac_of_mfma_peak"], 3)] if alt_unfused else None,
+        # ms per step with list_prep_img_proj [fp16 forced on, bf16x3 forced off] beside the modes' own lines above
+        "img_proj_ms": [round(alt_img_proj[headline]["ms_per_step"], 3), round(alt_img_proj[alt_prec]["ms_per_step"], 3)]
+                       if alt_img_proj else None,
         "gathers_ms": round(gather_ms, 4), "prep_ms": round(kernel_ms["prep_img_resize_nhwc"] + kernel_ms["prep_vox_ndhwc"], 4),
         "path_frac": round(path["whole_path_frac_of_binding_roof"], 3),
         "hbm_GB_step": round(path["hbm_bytes_per_step_pmc"] / 1e9, 2) if "hbm_bytes_per_step_pmc" in path else None,

@@ -34,10 +34,21 @@ constexpr int kFAOff = 2 * kFW;                     // A stages behind the two W
 __device__ __forceinline__ int fswz(int row) { return (row >> 1) & 7; }
 
 // per-thread record of one row's projection (project(), point_math.h), packed: what the four tap loads need
+// (valid: bit 0 = the row is a query point, bits 1..4 = Proj::dead, the taps outside the map)
 struct RowProj { int64_t base; int dx, dy; float w00, w01, w10, w11; int valid; };
+// the same per ROW of the tile, in LDS for the epilogue of the PROJ variant (48 B: three 16-B reads)
+struct RowProjRec { int64_t base; int dx, dy; float w00, w01, w10, w11; int valid, pad_[3]; };
+constexpr int kFProjRecOff = 81920;                 // behind the epilogue's staging tiles (8 waves x 32 x kStageLd floats)
 
-template <int X3>
+// PROJ (fp16 operands; list_prep_img_proj, ListQueryArgs.img_proj): the map holds fp.kept sampled channels followed by
+// N = 512 PROJECTED channels per pixel -- the low-resolution encoder levels already multiplied by their columns of
+// fc_0.  K-tiles 0 .. kept/64 - 1 are produced on chip as before, the projected levels' K-tiles do not exist (gp.k_gap),
+// and the epilogue adds the bilinear sample of the projected channels to the accumulators before bias and ReLU: in the
+// staged layout a thread owns (row, 8 consecutive columns) = (point, 8 consecutive projected channels), one 16-B load
+// per tap.  No 2-D gather kernel, no row-vector buffer.
+template <int X3, bool PROJ = false>
 __global__ __launch_bounds__(512, 2) void k_fc0_fused(FusedFc0Params fp) {
+  static_assert(!PROJ || X3 == 0, "the projected form is built for fp16 operands");
   constexpr bool F16 = X3 == 0;
   constexpr int KT = F16 ? 64 : 32;                 // feature columns per K-tile (128 operand bytes per row)
   using M = MapT<F16 ? 1 : 0>;
@@ -51,12 +62,15 @@ __global__ __launch_bounds__(512, 2) void k_fc0_fused(FusedFc0Params fp) {
   const int m0 = xcd_contiguous_block(blockIdx.x, ntiles) * 128;
   const int nk = p.K / KT;
   const int np = fp.n_produced;
-  const int64_t lda = (int64_t)p.K * (F16 ? 2 : 4), ldw = lda;      // bytes per operand row (hi + lo interleaved)
+  const int64_t lda = (int64_t)(p.lda ? p.lda : p.K) * (F16 ? 2 : 4), ldw = lda;      // bytes per operand row (hi + lo interleaved)
+  // byte offset of K-tile t in the operand rows (tiles from k_gap_at on lie k_gap tiles further: gemm_kernels.hip)
+  const int gap_at = p.k_gap_at, gap = p.k_gap;
+  auto ktb = [&](int t) { return (t + (t >= gap_at ? gap : 0)) * 128; };
 
   // ---- the two items of this thread in a produced K-tile: rows r0, r0 + 64, chunk c (16 B of map: 8 halfs / 4 floats)
   const int pc = tid & 7, pr = tid >> 3;
   RowProj rp[2];
-  if (np > 0) {
+  if (np > 0 || PROJ) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const Pt pt = load_point(fp.g, m0 + pr + 64 * h);
@@ -64,7 +78,7 @@ __global__ __launch_bounds__(512, 2) void k_fc0_fused(FusedFc0Params fp) {
       rp[h].base = (int64_t)pt.b * fp.ms * fp.ms * fp.Ct + q.o00 + pc * M::V;
       rp[h].dx = q.o01 - q.o00; rp[h].dy = q.o10 - q.o00;        // (o11 = o00 + dx + dy: x1, y1 are clamped separately)
       rp[h].w00 = q.w00; rp[h].w01 = q.w01; rp[h].w10 = q.w10; rp[h].w11 = q.w11;
-      rp[h].valid = pt.valid ? 1 : 0;
+      rp[h].valid = (pt.valid ? 1 : 0) | (q.dead << 1);
     }
   }
   typename M::Raw taps[2][4];
@@ -84,7 +98,7 @@ __global__ __launch_bounds__(512, 2) void k_fc0_fused(FusedFc0Params fp) {
       float r[M::V];
       tap_mul<M>(taps[h][0], rp[h].w00, r); tap_fma<M>(taps[h][1], rp[h].w01, r);
       tap_fma<M>(taps[h][2], rp[h].w10, r); tap_fma<M>(taps[h][3], rp[h].w11, r);
-      const bool v = rp[h].valid != 0;
+      const bool v = (rp[h].valid & 1) != 0;
       const int row = pr + 64 * h;
       if constexpr (F16) {
         const uint2 lo = half4_inrange(v ? make_float4(r[0], r[1], r[2], r[3]) : make_float4(0.f, 0.f, 0.f, 0.f));
@@ -109,7 +123,7 @@ __global__ __launch_bounds__(512, 2) void k_fc0_fused(FusedFc0Params fp) {
       const int piece = 8 * wave + r;
       const int row = piece * 8 + (lane >> 3);
       const int chunk = (lane & 7) ^ fswz(row);
-      glds16(p.w_hi + (int64_t)row * ldw + t * 128 + chunk * 16, wstage + piece * 1024);
+      glds16(p.w_hi + (int64_t)row * ldw + ktb(t) + chunk * 16, wstage + piece * 1024);
     }
   };
   auto stage_a = [&](int t, char* astage) {
@@ -119,7 +133,7 @@ __global__ __launch_bounds__(512, 2) void k_fc0_fused(FusedFc0Params fp) {
       const int row = piece * 8 + (lane >> 3);
       const int chunk = (lane & 7) ^ fswz(row);
       // (non-temporal like k_gemm_nt_pp's A stream: default policy measured 0.640 -> 0.651 ms, round 4)
-      glds16_nt(p.a_hi + (int64_t)min(m0 + row, a_last) * lda + t * 128 + chunk * 16, astage + piece * 1024);
+      glds16_nt(p.a_hi + (int64_t)min(m0 + row, a_last) * lda + ktb(t) + chunk * 16, astage + piece * 1024);
     }
   };
 
@@ -225,10 +239,38 @@ __global__ __launch_bounds__(512, 2) void k_fc0_fused(FusedFc0Params fp) {
     const int col_base = wn * 128;
     bool bad = false;
     __syncthreads();                                 // every wave is done with the operand stages
+    const RowProjRec* recs = (const RowProjRec*)(smem + kFProjRecOff);
+    if constexpr (PROJ) {
+      // the projections of the tile's 128 rows, from the threads that hold them (chunk 0 of rows pr and pr + 64)
+      if (pc == 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          RowProjRec rc;
+          rc.base = rp[h].base; rc.dx = rp[h].dx; rc.dy = rp[h].dy;
+          rc.w00 = rp[h].w00; rc.w01 = rp[h].w01; rc.w10 = rp[h].w10; rc.w11 = rp[h].w11; rc.valid = rp[h].valid;
+          rc.pad_[0] = rc.pad_[1] = rc.pad_[2] = 0;
+          *(RowProjRec*)(smem + kFProjRecOff + (pr + 64 * h) * (int)sizeof(RowProjRec)) = rc;
+        }
+      }
+      __syncthreads();
+    }
 #pragma unroll
     for (int ih = 0; ih < 2; ++ih)
 #pragma unroll
       for (int jh = 0; jh < 2; ++jh) {
+        // PROJ: the four taps of this turn's four (row, 8 projected channels) items, requested before the staging
+        [[maybe_unused]] uint4 ptap[4][4];
+        if constexpr (PROJ) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const RowProjRec& rc = recs[wm * 64 + ih * 32 + rr + 8 * k];
+            const int64_t o = rc.base + fp.kept + col_base + jh * 64 + c8;
+            ptap[k][0] = M::load(fp.img_map, o);
+            ptap[k][1] = M::load(fp.img_map, o + rc.dx);
+            ptap[k][2] = M::load(fp.img_map, o + rc.dy);
+            ptap[k][3] = M::load(fp.img_map, o + rc.dy + rc.dx);
+          }
+        }
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -247,8 +289,30 @@ __global__ __launch_bounds__(512, 2) void k_fc0_fused(FusedFc0Params fp) {
           const float4 y = *(const float4*)(tile + r * kStageLd + c8 + 4);
           const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
           float o[8];
+          if constexpr (PROJ) {
+            // the projected sample of (row, 8 channels): out-of-map taps masked like the reference (k_gather_img's
+            // OUT32 form, reduce_proj_exact), rows beyond the query contribute nothing; (acc + sample) + bias, the K sum
+            // first, as k_gemm_nt_pp's row-vector epilogue adds it
+            const RowProjRec& rc = recs[wm * 64 + ih * 32 + r];
+            const float wt[4] = {rc.w00, rc.w01, rc.w10, rc.w11};
+            float sm[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { o[e] = relu_nan(v[e] + bb[e]); bad = bad || (o[e] != o[e]); }
+            for (int e = 0; e < 8; ++e) sm[e] = 0.f;
+#pragma unroll
+            for (int tp = 0; tp < 4; ++tp) {
+              float f[8];
+              M::unpack(ptap[k][tp], f);
+              const bool dead = (rc.valid >> (1 + tp)) & 1;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) sm[e] = fmaf(dead ? 0.f : f[e], wt[tp], sm[e]);
+            }
+            const bool live = (rc.valid & 1) != 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { o[e] = relu_nan((v[e] + (live ? sm[e] : 0.f)) + bb[e]); bad = bad || (o[e] != o[e]); }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { o[e] = relu_nan(v[e] + bb[e]); bad = bad || (o[e] != o[e]); }
+          }
           store8_planes<F16 ? 1 : 0>(p.out_hi, F16 ? nullptr : p.out_lo, (row_base + ih * 32 + r) * p.ldo + cb, o);
         }
         __syncthreads();
@@ -259,8 +323,10 @@ __global__ __launch_bounds__(512, 2) void k_fc0_fused(FusedFc0Params fp) {
 }
 
 bool fused_fc0_eligible(const GemmParams& gp, int img_f16, int img_C) {
-  if (gp.N != 512 || gp.M <= 0 || gp.M % 128 || gp.K % 64 || img_C <= 0 || img_C % 64 || img_C > gp.K || !gp.bias ||
-      gp.rowvec || gp.lda || gp.ldw || gp.a_rows || gp.tile_gate) return false;
+  // (img_C: the channels produced on chip -- all of the perceptual block, or the kept levels of list_prep_img_proj)
+  if (gp.N != 512 || gp.M <= 0 || gp.M % 128 || gp.K % 64 || img_C < 0 || img_C % 64 || img_C > gp.K || !gp.bias ||
+      gp.rowvec || gp.a_rows || gp.tile_gate) return false;
+  if (gp.lda != gp.ldw || (gp.k_gap && !gp.lda)) return false;
   // fp16 operands pair with fp16 maps; the bf16 formats (interleaved hi / lo operands) with fp32 maps
   return gp.fmt == FMT_FP16 ? (img_f16 != 0 && !gp.x3i) : (img_f16 == 0 && gp.x3i != 0);
 }
@@ -268,9 +334,12 @@ bool fused_fc0_eligible(const GemmParams& gp, int img_f16, int img_C) {
 // terms: 3 = bf16x3, 1 = plain bf16 (split formats only)
 hipError_t launch_fc0_fused(const FusedFc0Params& fp, int terms, hipStream_t s) {
   const dim3 grid(fp.gp.M / 128);
-  if (fp.gp.fmt == FMT_FP16) hipLaunchKernelGGL(k_fc0_fused<0>, grid, dim3(512), 0, s, fp);
-  else if (terms == 3) hipLaunchKernelGGL(k_fc0_fused<3>, grid, dim3(512), 0, s, fp);
-  else hipLaunchKernelGGL(k_fc0_fused<1>, grid, dim3(512), 0, s, fp);
+  if (fp.proj) {
+    if (fp.gp.fmt != FMT_FP16 || fp.gp.N != 512) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_fc0_fused<0, true>), grid, dim3(512), 0, s, fp);
+  } else if (fp.gp.fmt == FMT_FP16) hipLaunchKernelGGL((k_fc0_fused<0, false>), grid, dim3(512), 0, s, fp);
+  else if (terms == 3) hipLaunchKernelGGL((k_fc0_fused<3, false>), grid, dim3(512), 0, s, fp);
+  else hipLaunchKernelGGL((k_fc0_fused<1, false>), grid, dim3(512), 0, s, fp);
   return hipGetLastError();
 }
 

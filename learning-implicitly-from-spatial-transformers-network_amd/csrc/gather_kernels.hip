@@ -784,7 +784,9 @@ __device__ __forceinline__ void fixup_level(const GatherParams& g, const ListVox
 
 template <int FMT, typename M>
 __device__ __forceinline__ void fixup_img(const GatherParams& g, const FixupArgs& fa, int blk, const Pt* pts) {
-  const int lq = fa.Ct / M::V;
+  // fa.Ct sampled channels go to X; the fa.Cs - fa.Ct channels behind them (list_prep_img_proj's projected sum: rowvec
+  // set) to the row vector -- the fused fc_0 samples those itself and writes no row vector, the gated re-run reads one
+  const int lq = (g.rowvec ? fa.Cs : fa.Ct) / M::V;
   const int64_t img_stride = (int64_t)fa.ms * fa.ms * fa.Cs;
   for (int item = threadIdx.x; item < kGatherRows * lq; item += 256) {
     const int local = item / lq, q = item - local * lq;
@@ -795,6 +797,14 @@ __device__ __forceinline__ void fixup_img(const GatherParams& g, const FixupArgs
                                   M::load(fa.img_map, bo + pr.o10), M::load(fa.img_map, bo + pr.o11)};
     float r[M::V];
     reduce_proj_exact<M>(v, pr, r);
+    if (q * M::V >= fa.Ct) {
+      float* dst = g.rowvec + (int64_t)(blk * kGatherRows + local) * g.rv_stride + (q * M::V - fa.Ct);
+#pragma unroll
+      for (int h = 0; h < M::V / 4; ++h)
+        *(float4*)(dst + 4 * h) = p.valid ? make_float4(r[4 * h], r[4 * h + 1], r[4 * h + 2], r[4 * h + 3])
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+      continue;
+    }
     store_feats<FMT, M::V>(g.x_hi, g.x_lo, (int64_t)(blk * kGatherRows + local) * g.Kp + fa.img_off + q * M::V, r,
                            p.valid);
   }
@@ -828,7 +838,6 @@ hipError_t launch_gather_fixup(const GatherParams& g, const FeatLayout& L, const
   fa.Cs = L.img_C;
   if (a.img_proj) {               // only the kept levels' columns are part of X (the projected sample is masked already)
     fa.Ct = a.img_kept_C; fa.Cs = a.img_kept_C + a.H1;
-    if (a.img_kept_C == 0) fa.img_map = nullptr;
   }
   fa.img_off = L.img_off; fa.clamp_hi = a.clamp_hi; fa.tile_flags = tile_flags;
   if (g.fmt == FMT_FP16)

@@ -186,7 +186,10 @@ int fused_fc0_mode() {
 }
 bool takes_fused_fc0_any(const ListQueryArgs* a, const FeatLayout& L) {
   if (fused_fc0_mode() == 0) return false;
-  if (a->percep_feat || a->percep_proj || a->img_proj) return false;
+  if (a->percep_feat || a->percep_proj) return false;
+  // list_prep_img_proj's map: the kept levels are produced on chip, the projected channels sampled in the epilogue
+  // (k_fc0_fused<0, true>: fp16 operands only)
+  if (a->img_proj && (a->precision != LIST_PREC_FP16 || fused_fc0_mode() == 2)) return false;
   // fp16 operands with fp16 maps, the bf16 formats with fp32 maps (the pairs the standard path takes too)
   if ((a->precision == LIST_PREC_FP16) != (a->img_dtype == LIST_MAP_F16)) return false;
   // bf16x3 keeps the unfused path: its packed weight is twice as long (hi + lo), and a 128-row tile streams ALL of it
@@ -199,7 +202,8 @@ bool takes_fused_fc0_any(const ListQueryArgs* a, const FeatLayout& L) {
   return a->H1 == 512 && a->img_C > 0 && a->img_C % 64 == 0 && L.img_off == 0 && L.Kp % 64 == 0;
 }
 int fused_produced_tiles(const ListQueryArgs* a) {
-  return fused_fc0_mode() == 2 ? 0 : a->img_C / (a->precision == LIST_PREC_FP16 ? 64 : 32);
+  const int channels = a->img_proj ? a->img_kept_C : a->img_C;
+  return fused_fc0_mode() == 2 ? 0 : channels / (a->precision == LIST_PREC_FP16 ? 64 : 32);
 }
 // true: the 2-D gather kernel is NOT launched (its columns are produced inside fc_0)
 bool takes_fused_fc0(const ListQueryArgs* a, const FeatLayout& L) {
@@ -656,6 +660,7 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
       gp.rowvec = (const char*)g.rowvec; gp.rowvec_stride = g.rv_stride * 4;
       if (a->H1 * 4 > L.Kp * 2) return fail(LIST_ERR_UNSUPPORTED, "img_proj: H1 * 4 bytes exceed a row of the feature matrix's lo plane");
     }
+    const char* rowvec_of_call = gp.rowvec;
     gp.out_hi = (unsigned short*)(wsb + ws.h1_hi);
     gp.out_lo = terms == 3 ? (unsigned short*)(wsb + ws.h1_lo) : nullptr;
     gp.ldo = a->H1;
@@ -669,7 +674,13 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
       FusedFc0Params fp;
       fp.gp = gp; fp.g = g; fp.img_map = a->img_map; fp.trans_mat = a->trans_mat;
       fp.ms = a->map_size; fp.Ct = a->img_C; fp.clamp_hi = a->clamp_hi; fp.n_produced = fused_produced_tiles(a);
-      if (!fused_fc0_eligible(gp, a->img_dtype == LIST_MAP_F16, a->img_C))
+      fp.proj = 0; fp.kept = 0;
+      if (a->img_proj) {
+        // the kernel samples the projected channels itself (no row-vector buffer); the exact redo below takes the row
+        // vectors the fix-up kernel writes for the tiles it flags
+        fp.proj = 1; fp.kept = a->img_kept_C; fp.Ct = a->img_kept_C + a->H1; fp.gp.rowvec = nullptr;
+      }
+      if (!fused_fc0_eligible(fp.gp, a->img_dtype == LIST_MAP_F16, a->img_proj ? a->img_kept_C : a->img_C))
         return fail(LIST_ERR_ARG, "internal: fused fc_0 taken for arguments it does not support");
       e = launch_fc0_fused(fp, terms, s);
     } else {
@@ -679,7 +690,7 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
     mark(LIST_STAGE_FC0);
     e = launch_gather_fixup(g, L, chunk_args, nan_tiles, s);
     if (e != hipSuccess) return hip_fail(e, "gather fix-up launch");
-    gp.nan_tiles = nullptr; gp.tile_gate = nan_tiles;
+    gp.nan_tiles = nullptr; gp.tile_gate = nan_tiles; gp.rowvec = rowvec_of_call;
     e = launch_gemm(gp, terms, EPI_RELU_SPLIT, s);
     if (e != hipSuccess) return hip_fail(e, "gated fc_0 launch");
     gp.tile_gate = nullptr; gp.x3i = 0;

@@ -494,6 +494,9 @@ struct FusedFc0Params {
   int ms, Ct; float clamp_hi;
   int n_produced;                // leading K-tiles produced on chip (Ct / 64, or Ct / 32 in the bf16 formats); 0: every
                                  //   K-tile from X (tile-shape diagnostic)
+  int proj, kept;                // proj = 1 (list_prep_img_proj's map, fp16 operands): Ct = kept + N channels per pixel,
+                                 //   n_produced = kept / 64, gp.k_gap_at / k_gap leave the projected levels' K-tiles out and
+                                 //   the epilogue adds the sample of the N projected channels
 };
 bool fused_fc0_eligible(const GemmParams& gp, int img_f16, int img_C);
 hipError_t launch_fc0_fused(const FusedFc0Params& fp, int terms, hipStream_t s);

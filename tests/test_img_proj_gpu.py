@@ -36,14 +36,14 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
 
 
-def run_proj(hip, inp, precision, query=None, n_kept=None, plan=None, sort=True, T=None):
+def run_proj(hip, inp, precision, query=None, n_kept=None, plan=None, sort=True, T=None, fused=True):
     md = hip.map_dtype_for(precision)
     vox = hip.prep_vox_maps(inp["vox"], md)
     packed = hip.prep_mlp_weights(inp["w"], vox.channels, sum(m.shape[1] for m in inp["img"]), precision)
     img = hip.prep_img_proj(inp["img"], packed, inp["map_size"], precision, n_kept_levels=n_kept)
     q = inp["query"] if query is None else query
     return hip.sdf_query(q, inp["T"] if T is None else T, img, vox, packed, precision=precision, clamp_hi=inp["clamp_hi"],
-                         plan=plan, sort_points=sort)
+                         plan=plan, sort_points=sort, fused_fc0=fused)
 
 
 def run_std(hip, inp, precision):
@@ -67,7 +67,15 @@ def test_golden_cases_against_the_oracle_and_the_standard_path(hip, precision):
         ref = O.list_query(c["query"], c["img_maps"], c["vox_maps"], c["trans_mat"], c["weights"])
         plan = {}
         got = run_proj(hip, inp, precision, plan=plan).cpu().numpy()
-        assert plan["img_proj"] == 1 and plan["fused_fc0"] == 0
+        # fp16: the kept levels are produced inside fc_0 and the projected channels sampled in its epilogue
+        # (k_fc0_fused<0, true>); the bf16 formats take k_gather_img + the row-vector epilogue of k_gemm_nt_pp
+        assert plan["img_proj"] == 1 and plan["fused_fc0"] == (1 if precision == "fp16" else 0)
+        if precision == "fp16":
+            plan_u = {}
+            unfused = run_proj(hip, inp, precision, plan=plan_u, fused=False).cpu().numpy()
+            assert plan_u["fused_fc0"] == 0 and plan_u["img_proj"] == 1
+            # same products, same k order, the sample added to the same sum: bit for bit
+            assert np.array_equal(got.view(np.uint32), unfused.view(np.uint32)), name
         kept = hip.img_proj_kept_levels(inp["img"], 137)
         kept_C = sum(m.shape[1] for m in inp["img"][:kept])
         assert plan["fc0_k"] == 3648 - (1024 - kept_C)
@@ -120,6 +128,7 @@ def test_config2_full_size(hip, precision):
     perm = torch.from_numpy(np.random.RandomState(0).permutation(20000)).to(DEV)
     assert torch.equal(run_proj(hip, inp, precision, inp["query"][:, perm].contiguous()), sdf[:, perm])
     assert torch.equal(run_proj(hip, inp, precision, sort=False), sdf)
+    assert torch.equal(run_proj(hip, inp, precision, fused=False), sdf)           # (fp16: the unfused pair, bit for bit)
     one = dict(inp, img=[m[5:6] for m in inp["img"]], vox=[m[5:6] for m in inp["vox"]], T=inp["T"][5:6],
                query=inp["query"][5:6])
     assert torch.equal(run_proj(hip, one, precision)[0], sdf[5])
@@ -154,6 +163,11 @@ def test_points_on_and_beyond_the_clamp_and_nan_coordinates(hip):
     assert np.isnan(got[0, 3]) and np.isnan(got).sum() == 1
     mask = np.ones_like(got, bool)
     mask[0, 3] = False
+    # fp16: the fused kernel writes no row vectors -- the exact redo of the NaN point's tile takes the fix-up kernel's
+    g16 = run_proj(hip, inp, "fp16", query=q).cpu().numpy()
+    b16 = run_proj(hip, inp, "fp16").cpu().numpy()
+    assert np.isnan(g16[0, 3]) and np.isnan(g16).sum() == 1
+    assert float(np.abs(g16[mask] - b16[mask]).max()) < 2e-4
     # (the NaN point's 256-row tile is redone with the reference's skip semantics, gather_kernels.hip k_gather_fixup: its
     # coarse levels then come from the per-sample form instead of the shared-tap one -- last-bit differences, as on the
     # standard path)
@@ -191,7 +205,7 @@ def test_module_api_takes_the_projection_for_inference_only(hip, monkeypatch):
 
 
 def test_argument_contract(hip):
-    inp, _ = case_inputs("tiny")
+    inp, _ = case_inputs("real")                       # (two kept levels: img_kept_C = 128)
     md = hip.map_dtype_for("bf16x3")
     vox = hip.prep_vox_maps(inp["vox"], md)
     packed = hip.prep_mlp_weights(inp["w"], vox.channels, 1024, "bf16x3")

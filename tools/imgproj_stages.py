@@ -56,7 +56,8 @@ if __name__ == "__main__":
     img_s = hip.prep_img_maps(maps, ms, md)
     img_p = hip.prep_img_proj(maps, packed, ms, prec)
     names = hip.STAGE_NAMES
-    for tag, img, fused in (("std-fused", img_s, True), ("std-unfused", img_s, False), ("proj", img_p, True)):
+    for tag, img, fused in (("std-fused", img_s, True), ("std-unfused", img_s, False), ("proj-fused", img_p, True),
+                            ("proj-unfused", img_p, False), ("std-fused", img_s, True), ("proj-fused", img_p, True)):
         t = stage_times(lambda arr: hip.sdf_query(q, T, img, vox, packed, precision=prec, stage_events=arr, fused_fc0=fused))
         tot = timed(lambda: hip.sdf_query(q, T, img, vox, packed, precision=prec, fused_fc0=fused), 20)
         print(tag, "query %.4f ms:" % tot, " ".join(f"{n}={v:.4f}" for n, v in zip(names, t) if v > 0))
