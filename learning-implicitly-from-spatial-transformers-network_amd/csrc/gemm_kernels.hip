@@ -393,9 +393,10 @@ __device__ __forceinline__ void staged_epilogue16(const f32x4v (&acc)[8][4], cha
 
 // epilogues of the 16x16 kernels: hidden layer (bias + ReLU + 16-bit planes, NaN probe), fp32 (diagnostic),
 // fused fc_2 + fc_out
+// dx_group: EPI_DX output of a grouped launch's product (null: p.dx)
 template <int EPI, int FP16>
 __device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4v (&acc)[8][4], char* smem, int m0, int n0,
-                                                int wm, int wn, int wave, int lane) {
+                                                int wm, int wn, int wave, int lane, void* dx_group = nullptr) {
   const int col_in = lane & 15, row_in = 4 * (lane >> 4);
   if (EPI == EPI_RELU_SPLIT) {
     const int64_t row_base = m0 + wm * 128;
@@ -479,15 +480,16 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4v (&ac
   } else if (EPI == EPI_DX) {
     const int64_t row_base = m0 + wm * 128;
     const int col_base = n0 + wn * 64;
+    void* const dx = dx_group ? dx_group : p.dx;
     staged_epilogue16(acc, smem, wave, lane, [&](int r, int c8, const float (&v)[8]) {
       if (col_base + c8 >= p.n_store) return;                  // n_store is a multiple of 8
       const int64_t off = (row_base + r) * p.ldo + col_base + c8;
       if (p.dx_f16) {
         const uint2 a = half4(make_float4(v[0], v[1], v[2], v[3])), b = half4(make_float4(v[4], v[5], v[6], v[7]));
-        *(uint4*)((unsigned short*)p.dx + off) = make_uint4(a.x, a.y, b.x, b.y);
+        *(uint4*)((unsigned short*)dx + off) = make_uint4(a.x, a.y, b.x, b.y);
       } else {
-        *(float4*)((float*)p.dx + off) = make_float4(v[0], v[1], v[2], v[3]);
-        *(float4*)((float*)p.dx + off + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        *(float4*)((float*)dx + off) = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)((float*)dx + off + 4) = make_float4(v[4], v[5], v[6], v[7]);
       }
     });
   } else if (EPI == EPI_F32) {
@@ -630,8 +632,32 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_pp(GemmParams p) {
   const int tiles_n = p.N / BN;
   const int ntiles = (p.M / BM) * tiles_n;
   const int tile = xcd_contiguous_block(blockIdx.x, ntiles);
-  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  int m0 = (tile / tiles_n) * BM;
+  const int n0 = (tile % tiles_n) * BN;
   if (p.tile_gate && p.tile_gate[tile / tiles_n] == 0) return;      // gated re-run (exact border semantics): uniform exit
+  // operands of this tile: the launch's, or (a grouped EPI_DX launch) those of the product the row tile belongs to --
+  // scalar selects over the kernel arguments at constant offsets (no indexed copy of the argument block)
+  const char* A = p.a_hi; const char* Wt = p.w_hi;
+  int Kk = p.K, lda_e = p.lda ? p.lda : p.K, a_rows_e = p.a_rows ? p.a_rows : p.M;
+  [[maybe_unused]] void* dx_out = p.dx;
+  if constexpr (EPI == EPI_DX) {
+    if (p.n_groups > 0) {
+      int mt = tile / tiles_n;
+      bool found = false;
+#pragma unroll
+      for (int i = 0; i < kGemmMaxGroups; ++i) {
+        if (!found && i < p.n_groups) {
+          if (mt < p.grp[i].m_tiles || i + 1 == p.n_groups) {
+            A = p.grp[i].a; Wt = p.grp[i].w; dx_out = p.grp[i].out; Kk = p.grp[i].K; a_rows_e = p.grp[i].a_rows;
+            lda_e = p.grp[i].lda; found = true;
+          } else {
+            mt -= p.grp[i].m_tiles;
+          }
+        }
+      }
+      m0 = mt * BM;
+    }
+  }
 
   // accumulators: 4x2 tiles of 32x32 (16 registers each) or 8x4 tiles of 16x16 (4 each); 128 registers either way
   typedef typename std::conditional<S16, f32x4v, f32x16>::type acc_t;
@@ -653,10 +679,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_pp(GemmParams p) {
   const int fswz = P::swz(frow);               // block row offsets are multiples of 16
   const int a_row_off = (wm * 128 + frow) * P::kRowBytes;
   const int w_row_off = (wn * 64 + frow) * P::kRowBytes;
-  const int64_t lda = (int64_t)(p.lda ? p.lda : p.K) * (X3 ? 4 : 2);      // bytes per operand row
+  const int64_t lda = (int64_t)lda_e * (X3 ? 4 : 2);      // bytes per operand row
   const int64_t ldw = (int64_t)(p.ldw ? p.ldw : p.K) * (X3 ? 4 : 2);
-  const int a_last = (p.a_rows ? p.a_rows : p.M) - 1;       // rows beyond the last existing one re-read it (outputs unused)
-  const int nk = X3 ? p.K / 32 : p.K / P::BK;              // K-tiles of 128 operand bytes per row
+  const int a_last = a_rows_e - 1;                         // rows beyond the last existing one re-read it (outputs unused)
+  const int nk = X3 ? Kk / 32 : Kk / P::BK;                // K-tiles of 128 operand bytes per row
 
   // one staging quarter = 16 pieces of 1 KB (8 rows of 128 B); this wave moves pieces 2 wave and 2 wave + 1
   auto stage_quarter = [&](char* sbase, int kbyte, int quarter) {
@@ -669,9 +695,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_pp(GemmParams p) {
       const int chunk = (lane % 8) ^ P::swz(row);
 #ifdef LIST_PP_A_RESIDENT     // ablation (wrong results): every tile stages the A rows of the first M-tile -- no HBM stream for A,
       // the LDS-DMA volume of a 128 x 512 tile that streams W twice and produces its A on chip
-      const char* g = (is_a ? p.a_hi + (int64_t)min(row, a_last) * lda : p.w_hi + (int64_t)(n0 + row) * ldw) + kbyte + chunk * 16;
+      const char* g = (is_a ? A + (int64_t)min(row, a_last) * lda : Wt + (int64_t)(n0 + row) * ldw) + kbyte + chunk * 16;
 #else
-      const char* g = (is_a ? p.a_hi + (int64_t)min(m0 + row, a_last) * lda : p.w_hi + (int64_t)(n0 + row) * ldw) + kbyte + chunk * 16;
+      const char* g = (is_a ? A + (int64_t)min(m0 + row, a_last) * lda : Wt + (int64_t)(n0 + row) * ldw) + kbyte + chunk * 16;
 #endif
 #ifndef LIST_PP_A_DEFAULT_POLICY
       if (EPI == EPI_RELU_SPLIT && is_a) glds16_nt(g, sbase + row0 * P::kRowBytes);
@@ -778,7 +804,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_pp(GemmParams p) {
   for (; t + 3 <= nk; ++t) k_tile(t, std::true_type());       // tiles 0 .. nk-3
   for (; t < nk; ++t) k_tile(t, std::false_type());           // the last two: fewer quarters left to fly
   if (wm == 0) __builtin_amdgcn_s_barrier();     // the first group waits for the second to catch up
-  if constexpr (S16) gemm_epilogue16<EPI, FP16>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+  if constexpr (S16) gemm_epilogue16<EPI, FP16>(p, acc, smem, m0, n0, wm, wn, wave, lane, dx_out);
   else gemm_epilogue<EPI, FP16>(p, acc, smem, m0, n0, wm, wn, wave, lane);
 }
 
@@ -1042,7 +1068,7 @@ static hipError_t launch_one(const GemmParams& p, hipStream_t s) {
   }
   if (p.x3i) return hipErrorInvalidValue;
   // operand strides, a row limit or a row vector exist in the ping-pong kernel only
-  const bool need_pp = p.lda || p.ldw || p.a_rows || p.rowvec || p.k_gap;
+  const bool need_pp = p.lda || p.ldw || p.a_rows || p.rowvec || p.k_gap || p.n_groups;
   // MFMA shape per epilogue (measured, fp16, P = 160k): 32x32x16 has the cheaper 64-B store runs on the short-K
   // layers (fc_1 0.074 vs 0.086 ms), 16x16x32 the cheaper row reduction of the fused fc_2 + fc_out epilogue (0.045
   // vs 0.058 ms) and, on the long-K ping-pong schedule, the higher clock (fc_0 0.55 -> 0.49 ms)
@@ -1096,6 +1122,16 @@ static hipError_t launch_epi(const GemmParams& p, int epi, hipStream_t s) {
 }
 
 hipError_t launch_gemm(const GemmParams& p, int terms, int epi, hipStream_t s) {
+  if (p.n_groups) {            // grouped launch: every group on its own terms, together M row tiles
+    if (epi != EPI_DX || p.n_groups < 0 || p.n_groups > kGemmMaxGroups) return hipErrorInvalidValue;
+    int tiles = 0;
+    for (int i = 0; i < p.n_groups; ++i) {
+      const GemmGroup& g = p.grp[i];
+      if (g.K % 64 || g.K <= 0 || g.m_tiles <= 0 || g.a_rows <= 0 || g.a_rows > g.m_tiles * BM || !g.a || !g.w || !g.out) return hipErrorInvalidValue;
+      tiles += g.m_tiles;
+    }
+    if (tiles * BM != p.M || p.plain_loop || !kPpShape16) return hipErrorInvalidValue;   // (the 16x16x32 ping-pong kernel only)
+  }
   if (p.M % BM || p.N % BN || p.K % 64 || p.M <= 0) return hipErrorInvalidValue;
   if (p.x3i && p.fmt == FMT_FP16) return hipErrorInvalidValue;
   if (epi == EPI_RELU_DOT && p.N != BN) return hipErrorInvalidValue;

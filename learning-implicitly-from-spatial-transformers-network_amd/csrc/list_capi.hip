@@ -485,7 +485,7 @@ int img_proj_plan(const ListMap2D* maps, int32_t B, int32_t n_kept, int32_t H1, 
     pl->rows[i] = rows; pl->rows_pad[i] = (rows + kRowTile - 1) / kRowTile * kRowTile;
     pl->a_f32[i] = fp16 ? 0 : take((size_t)rows * m.C * 4);
     pl->a_op[i] = take((size_t)rows * m.C * (fp16 ? 2 : 4));
-    pl->p[i] = take((size_t)pl->rows_pad[i] * H1 * 4);
+    pl->p[i] = take((size_t)pl->rows_pad[i] * H1 * (fp16 ? 2 : 4));       // projected level: halfs for fp16 operands
   }
   pl->scratch = o;
   return LIST_OK;
@@ -533,33 +533,46 @@ int list_prep_img_proj(const ListMap2D maps[LIST_N_IMG_LEVELS], int32_t B, int32
   if (e != hipSuccess) return hip_fail(e, "prep_img launch");
   ListMap2D proj[LIST_N_IMG_LEVELS];
   int coff = pl.kept_C, n_proj = 0;
+  char* sc = (char*)scratch;
+  // rows [B*H*W][C] of every projected level in the operand format (fp16, or bf16 hi / lo interleaved through an fp32
+  // staging copy): one launch
+  {
+    void* outs[LIST_N_IMG_LEVELS];
+    for (int i = n_kept_levels; i < LIST_N_IMG_LEVELS; ++i) outs[i - n_kept_levels] = fp16 ? sc + pl.a_op[i] : sc + pl.a_f32[i];
+    e = launch_img_level_rows(maps + n_kept_levels, outs, pl.n_proj, B, fp16 ? 1 : 0, s);
+    if (e != hipSuccess) return hip_fail(e, "level rows launch");
+  }
+  // P_l[pixel][n] = sum_c rows[pixel][c] * W0[n][coff_l + c]: every level in ONE grouped launch of the ping-pong kernel
+  // (fp16 operands: P_l in halfs, like the map it is resized into; bf16 formats: fp32)
+  GemmParams gp;
+  memset(&gp, 0, sizeof(gp));
+  gp.fmt = fp16 ? FMT_FP16 : FMT_BF16_SPLIT;
+  gp.x3i = fp16 ? 0 : 1;
+  gp.N = H1; gp.ldw = L.Kp; gp.dx_f16 = fp16 ? 1 : 0; gp.n_store = H1; gp.ldo = H1;
+  if (pl.n_proj > kGemmMaxGroups) return fail(LIST_ERR_UNSUPPORTED, "at most %d levels can be projected (n_kept_levels >= %d)", kGemmMaxGroups, LIST_N_IMG_LEVELS - kGemmMaxGroups);
+  int64_t m_total = 0;
   for (int i = n_kept_levels; i < LIST_N_IMG_LEVELS; ++i) {
     const ListMap2D& m = maps[i];
-    char* sc = (char*)scratch;
-    // rows [B*H*W][C] in the operand format (fp16, or bf16 hi / lo interleaved through an fp32 staging copy)
-    e = launch_img_level_rows(m, B, fp16 ? 1 : 0, fp16 ? sc + pl.a_op[i] : sc + pl.a_f32[i], s);
-    if (e != hipSuccess) return hip_fail(e, "level rows launch");
     if (!fp16) {
       e = launch_split_xi((const float*)(sc + pl.a_f32[i]), (unsigned short*)(sc + pl.a_op[i]), pl.rows[i] * m.C, s);
       if (e != hipSuccess) return hip_fail(e, "level split launch");
     }
-    // P_l[pixel][n] = sum_c rows[pixel][c] * W0[n][coff + c]  (fp32 out)
-    GemmParams gp;
-    memset(&gp, 0, sizeof(gp));
-    gp.fmt = fp16 ? FMT_FP16 : FMT_BF16_SPLIT;
-    gp.x3i = fp16 ? 0 : 1;
-    gp.a_hi = sc + pl.a_op[i]; gp.a_lo = gp.a_hi;
-    gp.w_hi = (const char*)packed_mlp + pk.w0_hi + (size_t)coff * (fp16 ? 2 : 4); gp.w_lo = gp.w_hi;
-    gp.M = (int)pl.rows_pad[i]; gp.N = H1; gp.K = m.C;
-    gp.lda = m.C; gp.ldw = L.Kp; gp.a_rows = (int)pl.rows[i];
-    gp.dx = sc + pl.p[i]; gp.dx_f16 = 0; gp.n_store = H1; gp.ldo = H1;
-    e = launch_gemm(gp, precision == LIST_PREC_BF16X3 ? 3 : 1, EPI_DX, s);
-    if (e != hipSuccess) return hip_fail(e, "level projection launch");
+    GemmGroup& gr = gp.grp[gp.n_groups++];
+    gr.a = sc + pl.a_op[i];
+    gr.w = (const char*)packed_mlp + pk.w0_hi + (size_t)coff * (fp16 ? 2 : 4);
+    gr.out = sc + pl.p[i]; gr.K = m.C; gr.a_rows = (int)pl.rows[i]; gr.m_tiles = (int)(pl.rows_pad[i] / kRowTile); gr.lda = m.C;
+    m_total += pl.rows_pad[i];
     ListMap2D& pm = proj[n_proj++];
     pm.data = (const float*)(sc + pl.p[i]); pm.C = H1; pm.H = m.H; pm.W = m.W;
     pm.sc = 1; pm.sw = H1; pm.sh = (int64_t)m.W * H1; pm.sb = (int64_t)m.H * m.W * H1;
     coff += m.C;
   }
+  if (m_total >= (int64_t)1 << 31) return fail(LIST_ERR_SHAPE, "projected levels too large");
+  gp.M = (int)m_total;
+  gp.a_hi = gp.grp[0].a; gp.a_lo = gp.a_hi; gp.w_hi = gp.grp[0].w; gp.w_lo = gp.w_hi; gp.dx = gp.grp[0].out;
+  gp.K = gp.grp[0].K; gp.lda = gp.grp[0].lda; gp.a_rows = gp.grp[0].a_rows;
+  e = launch_gemm(gp, precision == LIST_PREC_BF16X3 ? 3 : 1, EPI_DX, s);
+  if (e != hipSuccess) return hip_fail(e, "level projection launch");
   e = launch_proj_resize_sum(proj, n_proj, B, map_size, Ct, pl.kept_C, fp16 ? 1 : 0, out, s);
   if (e != hipSuccess) return hip_fail(e, "projected resize launch");
   return LIST_OK;

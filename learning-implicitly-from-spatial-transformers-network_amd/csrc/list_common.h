@@ -406,6 +406,10 @@ struct GatherParams {
   float* rowvec; int64_t rv_stride;   // projected perceptual sample: fp32 [rows][H1] row vectors (stride in floats), or null
 };
 
+// one product of a grouped launch (k_gemm_nt_pp, EPI_DX): its own operands, K and output, m_tiles row tiles of 256
+struct GemmGroup { const char* a; const char* w; void* out; int K, a_rows, m_tiles, lda; };
+constexpr int kGemmMaxGroups = LIST_N_IMG_LEVELS;     // (the projections of list_prep_img_proj: one per encoder level)
+
 struct GemmParams {
   const char* a_hi; const char* a_lo;     // [M][K] bf16
   const char* w_hi; const char* w_lo;     // [N][K] bf16
@@ -426,6 +430,10 @@ struct GemmParams {
   int lda, ldw;                                              // row strides of A / W in elements (0: K)
   int a_rows;                                                // rows of A that exist (0: M); staging re-reads the last one beyond
   const char* rowvec; int64_t rowvec_stride;                 // EPI_RELU_SPLIT: fp32 [M][N] row vectors added before the ReLU (byte stride), or null
+  // EPI_DX on the ping-pong kernel only: n_groups > 0 = several independent products in ONE launch (the projections of
+  // list_prep_img_proj: three small GEMMs, 17 - 19 us each as launches of their own).  M = 256 * sum of m_tiles; N, ldw,
+  // ldo, n_store, dx_f16, fmt, x3i are shared; a_hi / w_hi / dx / K / a_rows / lda come from the row tile's group
+  GemmGroup grp[kGemmMaxGroups]; int n_groups;
   int k_gap_at, k_gap;                                       // K-tiles (128 operand bytes per row) k_gap_at .. are read k_gap tiles further on in
                                                              //   A and W: fc_0 without the PROJECTED levels of its perceptual block
                                                              //   (list_prep_img_proj); K counts the tiles that are read.  0 / 0: none
@@ -451,9 +459,11 @@ struct GemmTnParams {
 hipError_t launch_prep_img(const ListMap2D maps[LIST_N_IMG_LEVELS], int B, int map_size, int Ct,
                            int f16, void* out, hipStream_t s, int n_levels = LIST_N_IMG_LEVELS);
 // list_prep_img_proj (prep_kernels.hip): encoder level [B,C,H,W] fp32 (any strides) -> rows [B*H*W][C], fp16 or fp32
-hipError_t launch_img_level_rows(const ListMap2D& m, int B, int f16, void* out, hipStream_t s);
-// out[b][y][x][coff + n] = sum_l resize(P_l)[b][y][x][n]: P_l = channels-last fp32 [B][H_l][W_l][H1] (n_src of them),
-// out = map with Ct channels per pixel (fp16 or fp32 elements); H1 % 64 == 0
+// (n levels in ONE launch: outs[i] receives maps[i])
+hipError_t launch_img_level_rows(const ListMap2D* maps, void* const* outs, int n, int B, int f16, hipStream_t s);
+// out[b][y][x][coff + n] = sum_l resize(P_l)[b][y][x][n]: P_l = channels-last [B][H_l][W_l][H1] (n_src of them), out =
+// map with Ct channels per pixel; f16: out AND the P_l are halfs (strides of `src` then count halfs), else both fp32;
+// H1 % 64 == 0
 hipError_t launch_proj_resize_sum(const ListMap2D* src, int n_src, int B, int map_size, int Ct, int coff, int f16,
                                   void* out, hipStream_t s);
 hipError_t launch_transpose_vox(const ListMap3D& m, int B, int f16, void* out, hipStream_t s);

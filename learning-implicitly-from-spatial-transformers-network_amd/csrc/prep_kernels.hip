@@ -4,6 +4,7 @@
 //   * 3-D maps: NCDHW -> NDHWC transpose through LDS
 //   * MLP parameters: column permutation + K padding + bf16 hi/lo split
 #include "list_common.h"
+#include "gather_math.h"
 
 namespace list {
 
@@ -492,13 +493,22 @@ hipError_t launch_prep_img(const ListMap2D maps[LIST_N_IMG_LEVELS], int B, int m
 // 3 - 13 MB per batch): lanes over pixels (coalesced along W on NCHW sources), 8 channels per thread.
 // grid = (ceil(H*W / 64), C / 8, B); block = 64.
 // --------------------------------------------------------------------------------------------
+struct LevelRowsArgs { ListMap2D m[LIST_N_IMG_LEVELS]; void* out[LIST_N_IMG_LEVELS]; int blk_begin[LIST_N_IMG_LEVELS + 1]; int n; };
+
+// grid = (sum over levels of ceil(H*W / 64), max C / 8, B): every projected level in ONE launch
 template <int F16>
-__global__ __launch_bounds__(64) void k_img_level_rows(ListMap2D m, void* __restrict__ out) {
-  const int px = blockIdx.x * 64 + threadIdx.x;
+__global__ __launch_bounds__(64) void k_img_level_rows(LevelRowsArgs a) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < LIST_N_IMG_LEVELS; ++i)
+    if (i < a.n && (int)blockIdx.x >= a.blk_begin[i]) l = i;
+  const ListMap2D m = a.m[l];
+  void* __restrict__ out = a.out[l];
+  const int px = ((int)blockIdx.x - a.blk_begin[l]) * 64 + threadIdx.x;
   const int npx = m.H * m.W;
-  if (px >= npx) return;
-  const int y = px / m.W, x = px - y * m.W;
   const int c0 = blockIdx.y * 8, b = blockIdx.z;
+  if (px >= npx || c0 >= m.C) return;
+  const int y = px / m.W, x = px - y * m.W;
   const float* src = m.data + (int64_t)b * m.sb + (int64_t)y * m.sh + (int64_t)x * m.sw + (int64_t)c0 * m.sc;
   float v[8];
 #pragma unroll
@@ -513,11 +523,23 @@ __global__ __launch_bounds__(64) void k_img_level_rows(ListMap2D m, void* __rest
   }
 }
 
-hipError_t launch_img_level_rows(const ListMap2D& m, int B, int f16, void* out, hipStream_t s) {
-  if (m.C % 8 || m.H < 1 || m.W < 1 || B < 1 || B > 65535 || m.C / 8 > 65535) return hipErrorInvalidValue;
-  const dim3 grid((unsigned)((m.H * m.W + 63) / 64), (unsigned)(m.C / 8), (unsigned)B);
-  if (f16) hipLaunchKernelGGL(k_img_level_rows<1>, grid, dim3(64), 0, s, m, out);
-  else hipLaunchKernelGGL(k_img_level_rows<0>, grid, dim3(64), 0, s, m, out);
+hipError_t launch_img_level_rows(const ListMap2D* maps, void* const* outs, int n, int B, int f16, hipStream_t s) {
+  if (n < 1 || n > LIST_N_IMG_LEVELS || B < 1 || B > 65535) return hipErrorInvalidValue;
+  LevelRowsArgs a;
+  a.n = n;
+  int blocks = 0, cmax = 0;
+  for (int i = 0; i < n; ++i) {
+    const ListMap2D& m = maps[i];
+    if (m.C % 8 || m.H < 1 || m.W < 1 || m.C / 8 > 65535) return hipErrorInvalidValue;
+    a.m[i] = m; a.out[i] = outs[i]; a.blk_begin[i] = blocks;
+    blocks += (m.H * m.W + 63) / 64;
+    cmax = m.C > cmax ? m.C : cmax;
+  }
+  for (int i = n; i < LIST_N_IMG_LEVELS; ++i) { a.m[i] = maps[0]; a.out[i] = outs[0]; a.blk_begin[i] = blocks; }
+  a.blk_begin[LIST_N_IMG_LEVELS] = blocks;
+  const dim3 grid((unsigned)blocks, (unsigned)(cmax / 8), (unsigned)B);
+  if (f16) hipLaunchKernelGGL(k_img_level_rows<1>, grid, dim3(64), 0, s, a);
+  else hipLaunchKernelGGL(k_img_level_rows<0>, grid, dim3(64), 0, s, a);
   return hipGetLastError();
 }
 
@@ -531,7 +553,8 @@ hipError_t launch_img_level_rows(const ListMap2D& m, int B, int f16, void* out, 
 constexpr int kProjMaxSrc = LIST_N_IMG_LEVELS;
 struct ProjSumArgs { ListMap2D src[kProjMaxSrc]; int n_src, B, ms, Ct, coff, H1, RY, nyt, nxt; };
 
-template <int F16>
+// NL = number of source levels (compile time: the per-level row pairs live in registers, 16 per level)
+template <int F16, int NL>
 __global__ __launch_bounds__(LIST_PREP_THREADS) void k_proj_resize_sum(ProjSumArgs a, void* __restrict__ out) {
   const int bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
   const int cgroups = a.H1 / kRowsCg;
@@ -547,13 +570,12 @@ __global__ __launch_bounds__(LIST_PREP_THREADS) void k_proj_resize_sum(ProjSumAr
   const int x = active ? xo : ms - 1;
   const int c = cg * kRowsCg + 8 * q;
 
-  float top[kProjMaxSrc][8], bot[kProjMaxSrc][8];
-  int row_top[kProjMaxSrc], row_bot[kProjMaxSrc];
-  const float* p0[kProjMaxSrc]; const float* p1[kProjMaxSrc];
-  float wx0[kProjMaxSrc], wx1[kProjMaxSrc], sy[kProjMaxSrc];
+  float top[NL][8], bot[NL][8];
+  int row_top[NL], row_bot[NL];
+  int64_t p0[NL], p1[NL];            // element offsets of the two x taps (row 0) in the level
+  float wx0[NL], wx1[NL], sy[NL];
 #pragma unroll
-  for (int l = 0; l < kProjMaxSrc; ++l) {
-    if (l >= a.n_src) break;
+  for (int l = 0; l < NL; ++l) {
     const ListMap2D& m = a.src[l];
     sy[l] = ms > 1 ? (float)(m.H - 1) / (float)(ms - 1) : 0.f;
     const float sx = ms > 1 ? (float)(m.W - 1) / (float)(ms - 1) : 0.f;
@@ -561,17 +583,27 @@ __global__ __launch_bounds__(LIST_PREP_THREADS) void k_proj_resize_sum(ProjSumAr
     const int x0 = min((int)fx, m.W - 1);
     const int x1 = x0 + (x0 < m.W - 1 ? 1 : 0);
     wx1[l] = fx - (float)x0; wx0[l] = 1.f - wx1[l];
-    p0[l] = m.data + (int64_t)b * m.sb + (int64_t)x0 * m.sw + c;
-    p1[l] = m.data + (int64_t)b * m.sb + (int64_t)x1 * m.sw + c;
+    p0[l] = (int64_t)b * m.sb + (int64_t)x0 * m.sw + c;
+    p1[l] = (int64_t)b * m.sb + (int64_t)x1 * m.sw + c;
     row_top[l] = -1; row_bot[l] = -1;
   }
+  // (F16: the projected levels are halfs too -- strides and offsets of `src` count ELEMENTS of that type; one 16-B load
+  // per tap instead of two)
   auto hrow = [&](int l, int r, float (&h)[8]) {
-    const float* r0 = p0[l] + (int64_t)r * a.src[l].sh;
-    const float* r1 = p1[l] + (int64_t)r * a.src[l].sh;
-    const float4 a0 = *(const float4*)r0, a1 = *(const float4*)(r0 + 4);
-    const float4 b0 = *(const float4*)r1, b1 = *(const float4*)(r1 + 4);
-    const float u[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-    const float v[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    float u[8], v[8];
+    if (F16) {
+      const unsigned short* r0 = (const unsigned short*)a.src[l].data + p0[l] + (int64_t)r * a.src[l].sh;
+      const unsigned short* r1 = (const unsigned short*)a.src[l].data + p1[l] + (int64_t)r * a.src[l].sh;
+      MapT<1>::unpack(*(const uint4*)r0, u);
+      MapT<1>::unpack(*(const uint4*)r1, v);
+    } else {
+      const float* r0 = a.src[l].data + p0[l] + (int64_t)r * a.src[l].sh;
+      const float* r1 = a.src[l].data + p1[l] + (int64_t)r * a.src[l].sh;
+      const float4 a0 = *(const float4*)r0, a1 = *(const float4*)(r0 + 4);
+      const float4 b0 = *(const float4*)r1, b1 = *(const float4*)(r1 + 4);
+      u[0] = a0.x; u[1] = a0.y; u[2] = a0.z; u[3] = a0.w; u[4] = a1.x; u[5] = a1.y; u[6] = a1.z; u[7] = a1.w;
+      v[0] = b0.x; v[1] = b0.y; v[2] = b0.z; v[3] = b0.w; v[4] = b1.x; v[5] = b1.y; v[6] = b1.z; v[7] = b1.w;
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) h[k] = u[k] * wx0[l] + v[k] * wx1[l];
   };
@@ -585,8 +617,7 @@ __global__ __launch_bounds__(LIST_PREP_THREADS) void k_proj_resize_sum(ProjSumAr
 #pragma unroll
     for (int k = 0; k < 8; ++k) o[k] = 0.f;
 #pragma unroll
-    for (int l = 0; l < kProjMaxSrc; ++l) {
-      if (l >= a.n_src) break;
+    for (int l = 0; l < NL; ++l) {
       const int H = a.src[l].H;
       const float fy = sy[l] * (float)y;
       const int y0 = min((int)fy, H - 1);
@@ -634,7 +665,8 @@ hipError_t launch_proj_resize_sum(const ListMap2D* src, int n_src, int B, int ma
   float sy_max = 0.f;
   for (int l = 0; l < n_src; ++l) {
     const ListMap2D& m = src[l];
-    if (m.C != a.H1 || m.sc != 1 || (m.sw % 4) || (m.sh % 4) || (m.sb % 4) || (reinterpret_cast<uintptr_t>(m.data) & 15))
+    const int al = f16 ? 8 : 4;               // elements per 16 bytes of the sources (halfs when the output is halfs)
+    if (m.C != a.H1 || m.sc != 1 || (m.sw % al) || (m.sh % al) || (m.sb % al) || (reinterpret_cast<uintptr_t>(m.data) & 15))
       return hipErrorInvalidValue;
     a.src[l] = m;
     const float sy = (float)(m.H - 1) / (float)(map_size - 1);
@@ -648,8 +680,14 @@ hipError_t launch_proj_resize_sum(const ListMap2D* src, int n_src, int B, int ma
   a.nxt = (map_size + kRowsPx - 1) / kRowsPx;
   const int64_t wgs = (int64_t)B * a.nyt * (a.H1 / kRowsCg) * a.nxt;
   if (wgs <= 0 || wgs >= 2147483647LL) return hipErrorInvalidValue;
-  if (f16) hipLaunchKernelGGL(k_proj_resize_sum<1>, dim3((unsigned)wgs), dim3(kRowsPx * 8), 0, s, a, out);
-  else hipLaunchKernelGGL(k_proj_resize_sum<0>, dim3((unsigned)wgs), dim3(kRowsPx * 8), 0, s, a, out);
+  const dim3 grid((unsigned)wgs), block(kRowsPx * 8);
+#define LIST_PROJ_SUM(NL)                                                                      \
+  case NL:                                                                                     \
+    if (f16) hipLaunchKernelGGL((k_proj_resize_sum<1, NL>), grid, block, 0, s, a, out);        \
+    else hipLaunchKernelGGL((k_proj_resize_sum<0, NL>), grid, block, 0, s, a, out);            \
+    break;
+  switch (n_src) { LIST_PROJ_SUM(1) LIST_PROJ_SUM(2) LIST_PROJ_SUM(3) LIST_PROJ_SUM(4) LIST_PROJ_SUM(5) default: return hipErrorInvalidValue; }
+#undef LIST_PROJ_SUM
   return hipGetLastError();
 }
 

@@ -286,14 +286,14 @@ def prep_img_maps(img_featuremaps, map_size=137, dtype="f32"):
 
 
 def img_proj_default(precision):
-    """Whether inference forwards through the module API take prep_img_proj for `precision`.  Measured at BASELINE
-    config 2 (B = 8, N = 20 000, 224^2; DESIGN 4 "Round 4b"): bf16x3 3.50 -> 3.17 ms, bf16 2.97 -> 2.77 ms; fp16 has
-    the 2-D sample inside fc_0 already (k_fc0_fused) and gains nothing.  LIST_IMG_PROJ=0 / 1 forces it off / on."""
+    """Whether inference forwards through the module API (and bench.py's modes) take prep_img_proj.  Measured at BASELINE
+    config 2 (B = 8, N = 20 000, 224^2; DESIGN 4 "Round 4b"): every precision gains -- bf16x3 3.50 -> 3.13 ms, bf16
+    2.97 -> 2.77 ms, fp16 1.99 -> 1.92 ms (there the kept levels are sampled inside fc_0 and the projected channels in
+    its epilogue, k_fc0_fused<0, true>).  LIST_IMG_PROJ=0 / 1 forces it off / on."""
     e = os.environ.get("LIST_IMG_PROJ", "")
     if e in ("0", "1"):
         return e == "1"
-    prec = PRECISIONS[precision] if isinstance(precision, str) else int(precision)
-    return prec != PREC_FP16
+    return True
 
 
 def img_proj_kept_levels(img_featuremaps, map_size=137):

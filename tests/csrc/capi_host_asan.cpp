@@ -169,6 +169,8 @@ int main() {
   e = a; e.no_fused_fc0 = 1;
   EXPECT(list_query_plan(&e, &pl) == LIST_OK && pl.fused_fc0 == 0 && pl.fused_tail == 1);
   e = a; e.img_proj = 1; e.img_kept_C = 128;                                  // fc_0 without the projected levels' 896 columns
+  EXPECT(list_query_plan(&e, &pl) == LIST_OK && pl.img_proj == 1 && pl.fc0_k == 3648 - 896 && pl.fused_fc0 == 1);
+  e.precision = LIST_PREC_BF16X3; e.img_dtype = LIST_MAP_F32;                 // the bf16 formats: 2-D gather + row-vector epilogue
   EXPECT(list_query_plan(&e, &pl) == LIST_OK && pl.img_proj == 1 && pl.fc0_k == 3648 - 896 && pl.fused_fc0 == 0);
   e = a; e.no_activations = 0;
   EXPECT(list_query_plan(&e, &pl) == LIST_OK && pl.fused_tail == 0 && pl.fused_fc0 == 0);

@@ -68,7 +68,7 @@ def test_abi_version_and_error_string_without_gpu():
     fp16_scratch = lib.list_img_proj_scratch_bytes(maps, 8, 2, 512, 2)
     rows = [8 * r * r for r in (56, 28, 14)]
     pad = [(x + 255) // 256 * 256 for x in rows]
-    assert fp16_scratch == sum(x * c * 2 + p * 512 * 4 for x, p, c in zip(rows, pad, (128, 256, 512)))
+    assert fp16_scratch == sum(x * c * 2 + p * 512 * 2 for x, p, c in zip(rows, pad, (128, 256, 512)))
     assert lib.list_img_proj_scratch_bytes(maps, 8, 2, 512, 0) > fp16_scratch
     assert lib.list_img_proj_map_bytes(maps, 8, 137, 5, 512, 0) == 0 and b"n_kept_levels" in lib.list_last_error()
     maps[3].C = 200
