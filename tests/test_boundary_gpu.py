@@ -53,7 +53,7 @@ def test_list_forward_matches_reference_model(net, golden_dir):
     net.cpu()
 
 
-def test_module_level_calls_equal_fused(net):
+def test_module_level_calls_equal_fused(net, monkeypatch):
     """executors.LIST.test of the reference calls percep_pooling then sdf_decoder by attribute."""
     net.to(DEV)
     img = torch.from_numpy(synth.uniform(78, (2, 3, 64, 64))).to(DEV)
@@ -65,8 +65,12 @@ def test_module_level_calls_equal_fused(net):
         percep = net.percep_pooling(feat_l2, p, tm)
         assert percep.shape == (2, 1024, 1, 333)
         two_step = net.sdf_decoder(p, vox_feat, percep.reshape(2, -1, 333))
-    # same kernels and same split of the same fp32 features -> identical
-    assert torch.equal(fused, two_step)
+        # an inference forward projects the low-resolution encoder levels through fc_0 before the resize (round 4b,
+        # hip.prep_img_proj): the same field, other rounding (fp32-grade operands: a few 1e-7)
+        assert float((fused - two_step).abs().max()) < 5e-6
+        # without it: the same kernels and the same split of the same fp32 features -> identical
+        monkeypatch.setenv("LIST_IMG_PROJ", "0")
+        assert torch.equal(net.query_sdf(q, feat_l2, vox_feat, tm), two_step)
     net.cpu()
 
 
