@@ -308,6 +308,7 @@ def run_config(args, precision, steps, warmup, inp, hip, ev, world, device, gath
     assert bool(plan.get("img_proj")) == img_proj, (plan, img_proj)
     if img_proj:
         kernel_ms["_img_proj"] = 1          # prep_img_resize_nhwc = resize of the kept levels + projections + their resized sum
+        kernel_ms["_fc0_k"] = plan["fc0_k"]  # K columns fc_0 runs over (the projected levels' are left out)
     if plan.get("fused_fc0"):
         # fc_0 produced the perceptual block of its A operand on chip (k_fc0_fused): no 2-D gather kernel ran
         kernel_ms["_fused_fc0"] = 1
@@ -577,11 +578,21 @@ def roofline_of(kernel_ms, table, precision, workload, batch):
     tail = "k_mlp_tail_f16 (fc_1 + ReLU + fc_2 + ReLU + fc_out)" if kernel_ms.get("_fused_tail") else "k_gemm_nt16 (fc_2 + ReLU + fc_out)"
     fc0 = ("k_fc0_fused (bilinear sample of the perceptual block into LDS + fc_0 + ReLU; the FLOPs are fc_0's)"
            if kernel_ms.get("_fused_fc0") else "k_gemm_nt_pp (fc_0 + ReLU)")
+    if kernel_ms.get("_img_proj"):
+        # list_prep_img_proj: the low-resolution encoder levels went through their fc_0 columns before the resize, so the
+        # kernel EXECUTES fewer products than the reference's fc_0 it replaces (`executed_flop_per_launch`); `achieved`
+        # stays the ALGORITHMIC rate (the reference op's FLOPs over the kernel's time), as the task defines it
+        fc0 = ("k_fc0_fused<0, true> (kept encoder levels sampled into LDS + fc_0 over the unprojected K-tiles + bilinear "
+               "sample of the projected levels in the epilogue + ReLU)" if kernel_ms.get("_fused_fc0")
+               else "k_gemm_nt_pp (fc_0 over the unprojected K-tiles + row-vector epilogue + ReLU)")
     r = {"kernel": {"fc_0": fc0, "fc_1": fc1, "fc_2_out": tail}[dom],
          "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
          "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "launches_per_step": launches,
          "launch_ms": kernel_ms[dom] / launches, "algorithmic_flop_per_launch": units / launches,
          "mfma_products_per_mac": 3 if precision == "bf16x3" else 1}
+    if dom == "fc_0" and kernel_ms.get("_fc0_k"):
+        r["executed_flop_per_launch"] = units / launches * kernel_ms["_fc0_k"] / 3648.0 * (3648.0 / 3610.0)
+        r["executed_k_of_3648"] = kernel_ms["_fc0_k"]
     assert 0.0 < r["frac"] <= 1.0, f"roofline fraction {r['frac']} is not physical: accounting bug"
     return r
 
@@ -804,8 +815,9 @@ def main():
         off_el, off_ms, off_sdf, _ = run_config(args, alt_prec, p_steps, min(args.warmup, 2), inp, hip, ev, world, device,
                                                 gather_fn, img_proj=not alt["kernel_ms"].get("_img_proj"))
         alt_img_proj = {
-            "what": "low-resolution encoder levels projected through fc_0 before the resize (list_prep_img_proj): "
-                    "default for the bf16 formats, off for fp16 (hip.img_proj_default)",
+            "what": "the same two modes with list_prep_img_proj switched the OTHER way (it is on by default for every "
+                    "precision, hip.img_proj_default): the low-resolution encoder levels go through their fc_0 columns "
+                    "before the resize",
             headline: {"img_proj": bool(on_ms.get("_img_proj")), "ms_per_step": on_el / p_steps * 1e3, "fc_0_ms": on_ms["fc_0"],
                        "prep_img_ms": on_ms["prep_img_resize_nhwc"], "gathers_ms": on_ms["gathers_back_to_back"],
                        "max_abs_diff_vs_mode": float((on_sdf - sdf).abs().max())},

@@ -260,7 +260,11 @@ __global__ __launch_bounds__(512, 2) void k_fc0_fused(FusedFc0Params fp) {
       for (int jh = 0; jh < 2; ++jh) {
         // PROJ: the four taps of this turn's four (row, 8 projected channels) items, requested before the staging
         [[maybe_unused]] uint4 ptap[4][4];
+#ifdef LIST_FUSED_PROJ_NO_SAMPLE        // ablation (wrong results): the epilogue without its tap loads
+        if constexpr (false) {
+#else
         if constexpr (PROJ) {
+#endif
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const RowProjRec& rc = recs[wm * 64 + ih * 32 + rr + 8 * k];
@@ -298,7 +302,13 @@ __global__ __launch_bounds__(512, 2) void k_fc0_fused(FusedFc0Params fp) {
             float sm[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) sm[e] = 0.f;
+#ifndef LIST_FUSED_PROJ_NO_SAMPLE
 #pragma unroll
+#else
+#pragma unroll
+            for (int tp = 0; tp < 0; ++tp) (void)tp;
+            if (false)
+#endif
             for (int tp = 0; tp < 4; ++tp) {
               float f[8];
               M::unpack(ptap[k][tp], f);

@@ -34,6 +34,8 @@ def kernel_key(name, grid, seq):
     if k == "k_fc0_fused":                    # fc_0 with the perceptual block produced on chip (fp16 inference forwards)
         return "fc_0"
     if k == "k_gemm_nt_pp":                   # ping-pong schedule: fc_0 (1250 tiles) and, in fp16, fc_1 (625 tiles)
+        if t.strip("<>").split(",")[0].strip() == "4":      # EPI_DX in a forward: the grouped level projections (list_prep_img_proj)
+            return "prep_img_proj_gemm"
         return "fc_0" if grid >= 600000 else "fc_1"
     if k in ("k_gemm_nt", "k_gemm_nt16"):
         epi = t.strip("<>").split(",")[1].strip()
@@ -55,6 +57,7 @@ def kernel_key(name, grid, seq):
             "k_transpose_vox_fused": "prep_vox_ndhwc_fused", "k_prep_img_rows": "prep_img_resize_nhwc_rows",
             "k_prep_img_tile": "prep_img_resize_nhwc", "k_prep_img": "prep_img_resize_nhwc",
             "k_gather_fixup": "exact_redo",
+            "k_img_level_rows": "prep_img_proj_rows", "k_proj_resize_sum": "prep_img_proj_sum",
             "k_sort_hist": "sort_points", "k_sort_scan": "sort_points", "k_sort_scatter": "sort_points"}.get(k)
 
 
@@ -96,6 +99,15 @@ def main():
         res[k] = {"hbm_bytes": 2 * f_kb * 1024 + w_kb * 1024, "fetch_size_kb_raw": f_kb,
                   "write_size_kb_raw": w_kb, "fetch_correction": 2.0,
                   "uncalibrated_writes": k == "fc_2_out" or k.startswith("gather")}
+    # list_prep_img_proj (round 4b): the 2-D prep is four launches of four kernels -- resize of the kept levels, operand
+    # rows, grouped projections, resized sum -- reported together under the name bench.py times them by
+    for part in ("prep_img_proj_rows", "prep_img_proj_gemm", "prep_img_proj_sum"):
+        if part in res:
+            tgt = res.setdefault("prep_img_resize_nhwc", {"hbm_bytes": 0.0, "fetch_size_kb_raw": 0.0, "write_size_kb_raw": 0.0,
+                                                          "fetch_correction": 2.0, "uncalibrated_writes": False})
+            for f in ("hbm_bytes", "fetch_size_kb_raw", "write_size_kb_raw"):
+                tgt[f] += res[part][f]
+            tgt.setdefault("parts", {})[part] = res.pop(part)["hbm_bytes"]
     data = json.load(open(out)) if os.path.exists(out) else {}
     # what the counters were measured ON: the SHA-256 of the kernel sources (build.py); bench.py drops `traffic` when
     # the library it runs was built from other sources
