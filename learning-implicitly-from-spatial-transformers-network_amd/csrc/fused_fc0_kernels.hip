@@ -258,7 +258,10 @@ __global__ __launch_bounds__(512, 2) void k_fc0_fused(FusedFc0Params fp) {
     for (int ih = 0; ih < 2; ++ih)
 #pragma unroll
       for (int jh = 0; jh < 2; ++jh) {
-        // PROJ: the four taps of this turn's four (row, 8 projected channels) items, requested before the staging
+        // PROJ: the four taps of this turn's four (row, 8 projected channels) items, requested before the staging.
+        // (Round 4b, one box, two interleaved pairs: the sampling costs 0.07 ms of the kernel's 0.545 -- without the
+        // loads 0.474 --; requesting turn t + 1's taps behind turn t's staging stores, two tap buffers, made it SLOWER,
+        // 0.545 -> 0.563 ms with 108 instead of 68 B of scratch: not round-trip latency, the bytes themselves.)
         [[maybe_unused]] uint4 ptap[4][4];
 #ifdef LIST_FUSED_PROJ_NO_SAMPLE        // ablation (wrong results): the epilogue without its tap loads
         if constexpr (false) {
