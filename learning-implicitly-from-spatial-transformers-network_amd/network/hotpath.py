@@ -206,16 +206,15 @@ def sdf_query(query, trans_mat, img_maps, vox_maps, mlp_params, *, perm=(2, 1, 0
     mlp = [mlp_params[k] for k in MLP_KEYS]
     md = hip.map_dtype_for(precision)
     img_maps = [_f32(m) for m in img_maps] if percep_feat is None else []
-    vox = caches.setdefault("vox:" + md, _Cache()).get(
-        vox_maps, lambda: hip.prep_vox_maps([v.detach() for v in vox_maps], md))
     img_C = sum(m.shape[1] for m in img_maps) if percep_feat is None else percep_feat.shape[1]
+    vox_C = [int(v.shape[1]) for v in vox_maps]
     mlp_dict = {k: t.detach() for k, t in zip(MLP_KEYS, mlp)}
     training = torch.is_grad_enabled() and any(t.requires_grad for t in mlp)
     if training:          # parameters move every step (and `.data` writes are invisible to a cache): pack afresh
-        packed = hip.prep_mlp_weights(mlp_dict, vox.channels, img_C, precision)
+        packed = hip.prep_mlp_weights(mlp_dict, vox_C, img_C, precision)
     else:
         packed = caches.setdefault("mlp:" + str(precision), _Cache()).get(
-            mlp, lambda: hip.prep_mlp_weights(mlp_dict, vox.channels, img_C, precision))
+            mlp, lambda: hip.prep_mlp_weights(mlp_dict, vox_C, img_C, precision))
     diff = [t for t in (trans_mat, percep_feat, *img_maps, *vox_maps, *mlp)
             if t is not None and t.requires_grad]
     inference = not (torch.is_grad_enabled() and diff)
@@ -240,6 +239,10 @@ def sdf_query(query, trans_mat, img_maps, vox_maps, mlp_params, *, perm=(2, 1, 0
     if percep_feat is None and img is None:
         img = caches.setdefault("img:" + md, _Cache()).get(
             img_maps, lambda: hip.prep_img_maps([m.detach() for m in img_maps], map_size, md))
+    # (the 2-D side first: its kernels are the call's first launches -- channels-last encoders make the 3-D hand-off below
+    # a zero-copy with no launch at all, and the host work in between would otherwise sit in front of an idle device)
+    vox = caches.setdefault("vox:" + md, _Cache()).get(
+        vox_maps, lambda: hip.prep_vox_maps([v.detach() for v in vox_maps], md))
 
     def run():
         proj = None
@@ -270,10 +273,10 @@ def sdf_query(query, trans_mat, img_maps, vox_maps, mlp_params, *, perm=(2, 1, 0
         # the transposed copies for the data gradients are taken NOW, from the same parameter values as `packed`
         # (a lazy build at backward time could see parameters an optimizer or EMA step has moved in between)
         if training:
-            packed_b = hip.prep_mlp_weights_bwd(mlp_dict, vox.channels, img_C, precision)
+            packed_b = hip.prep_mlp_weights_bwd(mlp_dict, vox_C, img_C, precision)
         else:
             packed_b = caches.setdefault("mlpT:" + str(precision), _Cache()).get(
-                mlp, lambda: hip.prep_mlp_weights_bwd(mlp_dict, vox.channels, img_C, precision))
+                mlp, lambda: hip.prep_mlp_weights_bwd(mlp_dict, vox_C, img_C, precision))
 
         def packed_bwd():
             return packed_b
