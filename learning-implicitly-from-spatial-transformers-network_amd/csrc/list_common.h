@@ -462,10 +462,10 @@ hipError_t launch_prep_img(const ListMap2D maps[LIST_N_IMG_LEVELS], int B, int m
 // (n levels in ONE launch: outs[i] receives maps[i])
 hipError_t launch_img_level_rows(const ListMap2D* maps, void* const* outs, int n, int B, int f16, hipStream_t s);
 // out[b][y][x][coff + n] = sum_l resize(P_l)[b][y][x][n]: P_l = channels-last [B][H_l][W_l][H1] (n_src of them), out =
-// map with Ct channels per pixel; f16: out AND the P_l are halfs (strides of `src` then count halfs), else both fp32;
+// map with Ct channels per pixel; f16: out is halfs; src_f16: the P_l are halfs (strides of `src` then count halfs);
 // H1 % 64 == 0
 hipError_t launch_proj_resize_sum(const ListMap2D* src, int n_src, int B, int map_size, int Ct, int coff, int f16,
-                                  void* out, hipStream_t s);
+                                  void* out, hipStream_t s, int src_f16);
 hipError_t launch_transpose_vox(const ListMap3D& m, int B, int f16, void* out, hipStream_t s);
 // the levels for which transpose_tile_eligible() holds, all in one launch
 bool transpose_tile_eligible(const ListMap3D& m, const void* out);

@@ -554,7 +554,7 @@ constexpr int kProjMaxSrc = LIST_N_IMG_LEVELS;
 struct ProjSumArgs { ListMap2D src[kProjMaxSrc]; int n_src, B, ms, Ct, coff, H1, RY, nyt, nxt; };
 
 // NL = number of source levels (compile time: the per-level row pairs live in registers, 16 per level)
-template <int F16, int NL>
+template <int F16, int NL, int SRC16>
 __global__ __launch_bounds__(LIST_PREP_THREADS) void k_proj_resize_sum(ProjSumArgs a, void* __restrict__ out) {
   const int bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
   const int cgroups = a.H1 / kRowsCg;
@@ -587,11 +587,11 @@ __global__ __launch_bounds__(LIST_PREP_THREADS) void k_proj_resize_sum(ProjSumAr
     p1[l] = (int64_t)b * m.sb + (int64_t)x1 * m.sw + c;
     row_top[l] = -1; row_bot[l] = -1;
   }
-  // (F16: the projected levels are halfs too -- strides and offsets of `src` count ELEMENTS of that type; one 16-B load
-  // per tap instead of two)
+  // (SRC16: the projected levels are halfs -- strides and offsets of `src` count ELEMENTS of that type; one 16-B load per
+  // tap instead of two)
   auto hrow = [&](int l, int r, float (&h)[8]) {
     float u[8], v[8];
-    if (F16) {
+    if (SRC16) {
       const unsigned short* r0 = (const unsigned short*)a.src[l].data + p0[l] + (int64_t)r * a.src[l].sh;
       const unsigned short* r1 = (const unsigned short*)a.src[l].data + p1[l] + (int64_t)r * a.src[l].sh;
       MapT<1>::unpack(*(const uint4*)r0, u);
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(LIST_PREP_THREADS) void k_proj_resize_sum(ProjSumAr
 }
 
 hipError_t launch_proj_resize_sum(const ListMap2D* src, int n_src, int B, int map_size, int Ct, int coff, int f16,
-                                  void* out, hipStream_t s) {
+                                  void* out, hipStream_t s, int src_f16) {
   if (n_src < 1 || n_src > kProjMaxSrc || map_size < 2 || B < 1) return hipErrorInvalidValue;
   ProjSumArgs a;
   a.n_src = n_src; a.B = B; a.ms = map_size; a.Ct = Ct; a.coff = coff; a.H1 = src[0].C;
@@ -665,7 +665,7 @@ hipError_t launch_proj_resize_sum(const ListMap2D* src, int n_src, int B, int ma
   float sy_max = 0.f;
   for (int l = 0; l < n_src; ++l) {
     const ListMap2D& m = src[l];
-    const int al = f16 ? 8 : 4;               // elements per 16 bytes of the sources (halfs when the output is halfs)
+    const int al = src_f16 ? 8 : 4;           // elements per 16 bytes of the sources
     if (m.C != a.H1 || m.sc != 1 || (m.sw % al) || (m.sh % al) || (m.sb % al) || (reinterpret_cast<uintptr_t>(m.data) & 15))
       return hipErrorInvalidValue;
     a.src[l] = m;
@@ -685,8 +685,10 @@ hipError_t launch_proj_resize_sum(const ListMap2D* src, int n_src, int B, int ma
   const dim3 grid((unsigned)wgs), block(kRowsPx * 8);
 #define LIST_PROJ_SUM(NL)                                                                      \
   case NL:                                                                                     \
-    if (f16) hipLaunchKernelGGL((k_proj_resize_sum<1, NL>), grid, block, 0, s, a, out);        \
-    else hipLaunchKernelGGL((k_proj_resize_sum<0, NL>), grid, block, 0, s, a, out);            \
+    if (f16 && src_f16) hipLaunchKernelGGL((k_proj_resize_sum<1, NL, 1>), grid, block, 0, s, a, out);   \
+    else if (f16) hipLaunchKernelGGL((k_proj_resize_sum<1, NL, 0>), grid, block, 0, s, a, out);         \
+    else if (src_f16) return hipErrorInvalidValue;                                                       \
+    else hipLaunchKernelGGL((k_proj_resize_sum<0, NL, 0>), grid, block, 0, s, a, out);                  \
     break;
   switch (n_src) { LIST_PROJ_SUM(1) LIST_PROJ_SUM(2) LIST_PROJ_SUM(3) LIST_PROJ_SUM(4) LIST_PROJ_SUM(5) default: return hipErrorInvalidValue; }
 #undef LIST_PROJ_SUM

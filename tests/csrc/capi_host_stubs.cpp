@@ -15,7 +15,7 @@ namespace list {
 #define STUB(sig, name) sig { reached(name); }
 STUB(hipError_t launch_prep_img(const ListMap2D*, int, int, int, int, void*, hipStream_t, int), "launch_prep_img")
 STUB(hipError_t launch_img_level_rows(const ListMap2D*, void* const*, int, int, int, hipStream_t), "launch_img_level_rows")
-STUB(hipError_t launch_proj_resize_sum(const ListMap2D*, int, int, int, int, int, int, void*, hipStream_t), "launch_proj_resize_sum")
+STUB(hipError_t launch_proj_resize_sum(const ListMap2D*, int, int, int, int, int, int, void*, hipStream_t, int), "launch_proj_resize_sum")
 STUB(hipError_t launch_transpose_vox(const ListMap3D&, int, int, void*, hipStream_t), "launch_transpose_vox")
 bool transpose_tile_eligible(const ListMap3D&, const void*) { return false; }
 STUB(hipError_t launch_transpose_vox_fused(const ListMap3D*, void* const*, const int*, int, int, hipStream_t), "launch_transpose_vox_fused")
