@@ -888,7 +888,7 @@ static hipError_t launch_vox_level(const GatherParams& g, const ListVoxLevel& lv
 }
 
 #ifndef LIST_GATHER_SEQ
-#define LIST_GATHER_SEQ 45I123T
+#define LIST_GATHER_SEQ 123I45T
 #endif
 #define LIST_STR2(x) #x
 #define LIST_STR(x) LIST_STR2(x)
@@ -996,6 +996,10 @@ static hipError_t launch_gather_fmt(const GatherParams& g, const FeatLayout& L, 
   // one device (tools/ab_gather.sh): with the coarse levels LAST the group takes 0.79-0.83 instead of 0.85-0.87 ms and
   // fc_0 behind it 0.50-0.53 instead of 0.48 ms -- group + fc_0 = 1.34-1.35 ms whatever the order (the X lines the
   // gathers leave dirty in the L2s drain into whatever runs next), the step 2.04-2.10 ms.  Kept: the round-2 order
+  // Round 4b: with the 2-D sample inside fc_0 and fc_0 short of its projected K-tiles (fp16 inference forwards) the
+  // balance moved: the fine levels FIRST and the matrix-core levels last, 123I45T, takes the fp16 step from 1.944 / 1.951
+  // to 1.930 / 1.922 ms (group -0.05, fc_0 +0.02; two interleaved repetitions, tools/r4b_seq_ab.sh); bf16x3 and the training
+  // step inside their noise, plain bf16 +0.02.  Now the default.
   // (Round 4, measured and dropped: the seven gathers spread over two to four QUEUES -- side streams forked and joined
   // around this group -- run side by side (group 0.85 -> 0.79 ms) but every launch around them pays for the fork / join
   // (sort, fc_0, tail, the preps of the next step): step 2.08 -> 2.08 ... 2.18 ms over five assignments.)
