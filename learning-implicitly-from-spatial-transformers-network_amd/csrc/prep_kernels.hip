@@ -491,29 +491,42 @@ hipError_t launch_prep_img(const ListMap2D maps[LIST_N_IMG_LEVELS], int B, int m
 // list_prep_img_proj: an encoder level [B,C,H,W] fp32 (any strides) -> the A operand of its projection, rows
 // [B*H*W][C] (fp16, or fp32 for the split formats).  The levels this runs on are small (14^2 ... 56^2 pixels,
 // 3 - 13 MB per batch): lanes over pixels (coalesced along W on NCHW sources), 8 channels per thread.
-// grid = (ceil(H*W / 64), C / 8, B); block = 64.
 // --------------------------------------------------------------------------------------------
-struct LevelRowsArgs { ListMap2D m[LIST_N_IMG_LEVELS]; void* out[LIST_N_IMG_LEVELS]; int blk_begin[LIST_N_IMG_LEVELS + 1]; int n; };
+struct LevelRowsArgs { ListMap2D m[LIST_N_IMG_LEVELS]; void* out[LIST_N_IMG_LEVELS]; int blk_begin[LIST_N_IMG_LEVELS + 1]; int n, B; };
 
-// grid = (sum over levels of ceil(H*W / 64), max C / 8, B): every projected level in ONE launch
+// one launch for every projected level; a workgroup = 32 pixels x 64 channels of one image: reads run along the pixels
+// (NCHW sources) or along the channels (channels-last ones), the [32][64] tile turns through LDS, writes are whole
+// 128-B (fp16) / 256-B rows of 64 channels.  blockIdx.x walks (level | image, pixel block, channel group)
 template <int F16>
-__global__ __launch_bounds__(64) void k_img_level_rows(LevelRowsArgs a) {
+__global__ __launch_bounds__(256) void k_img_level_rows(LevelRowsArgs a) {
+  __shared__ float tile[32][65];
   int l = 0;
 #pragma unroll
   for (int i = 1; i < LIST_N_IMG_LEVELS; ++i)
     if (i < a.n && (int)blockIdx.x >= a.blk_begin[i]) l = i;
   const ListMap2D m = a.m[l];
   void* __restrict__ out = a.out[l];
-  const int px = ((int)blockIdx.x - a.blk_begin[l]) * 64 + threadIdx.x;
-  const int npx = m.H * m.W;
-  const int c0 = blockIdx.y * 8, b = blockIdx.z;
-  if (px >= npx || c0 >= m.C) return;
-  const int y = px / m.W, x = px - y * m.W;
-  const float* src = m.data + (int64_t)b * m.sb + (int64_t)y * m.sh + (int64_t)x * m.sw + (int64_t)c0 * m.sc;
+  const int npx = m.H * m.W, cgs = m.C / 64, pbs = (npx + 31) / 32;
+  int idx = (int)blockIdx.x - a.blk_begin[l];
+  const int cg = idx % cgs; idx /= cgs;
+  const int pb = idx % pbs;
+  const int b = idx / pbs;
+  const int c0 = cg * 64, p0 = pb * 32;
+  {
+    const int pp = threadIdx.x & 31, oc = threadIdx.x >> 5;            // pixel, channel octet
+    const int px = min(p0 + pp, npx - 1);
+    const int y = px / m.W, x = px - y * m.W;
+    const float* src = m.data + (int64_t)b * m.sb + (int64_t)y * m.sh + (int64_t)x * m.sw + (int64_t)(c0 + 8 * oc) * m.sc;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tile[pp][8 * oc + k] = src[(int64_t)k * m.sc];
+  }
+  __syncthreads();
+  const int pp = threadIdx.x >> 3, ch = threadIdx.x & 7;               // pixel, 8-channel chunk
+  if (p0 + pp >= npx) return;
   float v[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) v[k] = src[(int64_t)k * m.sc];
-  const int64_t o = ((int64_t)b * npx + px) * m.C + c0;
+  for (int k = 0; k < 8; ++k) v[k] = tile[pp][8 * ch + k];
+  const int64_t o = ((int64_t)b * npx + p0 + pp) * m.C + c0 + 8 * ch;
   if (F16) {
     const uint2 lo = half4(make_float4(v[0], v[1], v[2], v[3])), hi = half4(make_float4(v[4], v[5], v[6], v[7]));
     *(uint4*)((unsigned short*)out + o) = make_uint4(lo.x, lo.y, hi.x, hi.y);
@@ -524,22 +537,21 @@ __global__ __launch_bounds__(64) void k_img_level_rows(LevelRowsArgs a) {
 }
 
 hipError_t launch_img_level_rows(const ListMap2D* maps, void* const* outs, int n, int B, int f16, hipStream_t s) {
-  if (n < 1 || n > LIST_N_IMG_LEVELS || B < 1 || B > 65535) return hipErrorInvalidValue;
+  if (n < 1 || n > LIST_N_IMG_LEVELS || B < 1) return hipErrorInvalidValue;
   LevelRowsArgs a;
-  a.n = n;
-  int blocks = 0, cmax = 0;
+  a.n = n; a.B = B;
+  int64_t blocks = 0;
   for (int i = 0; i < n; ++i) {
     const ListMap2D& m = maps[i];
-    if (m.C % 8 || m.H < 1 || m.W < 1 || m.C / 8 > 65535) return hipErrorInvalidValue;
-    a.m[i] = m; a.out[i] = outs[i]; a.blk_begin[i] = blocks;
-    blocks += (m.H * m.W + 63) / 64;
-    cmax = m.C > cmax ? m.C : cmax;
+    if (m.C % 64 || m.H < 1 || m.W < 1) return hipErrorInvalidValue;
+    a.m[i] = m; a.out[i] = outs[i]; a.blk_begin[i] = (int)blocks;
+    blocks += (int64_t)B * ((m.H * m.W + 31) / 32) * (m.C / 64);
+    if (blocks >= 2147483647LL) return hipErrorInvalidValue;
   }
-  for (int i = n; i < LIST_N_IMG_LEVELS; ++i) { a.m[i] = maps[0]; a.out[i] = outs[0]; a.blk_begin[i] = blocks; }
-  a.blk_begin[LIST_N_IMG_LEVELS] = blocks;
-  const dim3 grid((unsigned)blocks, (unsigned)(cmax / 8), (unsigned)B);
-  if (f16) hipLaunchKernelGGL(k_img_level_rows<1>, grid, dim3(64), 0, s, a);
-  else hipLaunchKernelGGL(k_img_level_rows<0>, grid, dim3(64), 0, s, a);
+  for (int i = n; i < LIST_N_IMG_LEVELS; ++i) { a.m[i] = maps[0]; a.out[i] = outs[0]; a.blk_begin[i] = (int)blocks; }
+  a.blk_begin[LIST_N_IMG_LEVELS] = (int)blocks;
+  if (f16) hipLaunchKernelGGL(k_img_level_rows<1>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_img_level_rows<0>, dim3((unsigned)blocks), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
