@@ -632,13 +632,17 @@ int list_sdf_query_fwd(const ListQueryArgs* a, void* stream) {
     hipError_t e = hipSuccess;
     if (!a->no_sort) {
       SortBuffers sb;
-      sb.order = (int*)(wsb + ws.order); sb.order_img = (int*)(wsb + ws.order_img);
+      // the pixel order serves the 2-D gather kernel (and, behind a training forward, the backward's map-side gather):
+      // a forward whose fc_0 samples the map itself (k_fc0_fused) sorts by Morton cell only -- no projection per point,
+      // half the counters, one scan and two index arrays less
+      const bool want_pix = !takes_fused_fc0(a, L);
+      sb.order = (int*)(wsb + ws.order); sb.order_img = want_pix ? (int*)(wsb + ws.order_img) : nullptr;
       sb.row_of = (int*)(wsb + ws.row_of); sb.keys = (int*)(wsb + ws.keys);
       sb.keys2 = (int*)(wsb + ws.keys2); sb.bins = (int*)(wsb + ws.bins);
       e = launch_sort_points(g, *a, sb, s);
       if (e != hipSuccess) return hip_fail(e, "sort launch");
       g.order = sb.order;
-      if (a->percep_feat == nullptr && a->map_size * ((a->map_size + 3) / 4) <= kSortPixCells) {
+      if (want_pix && a->percep_feat == nullptr && a->map_size * ((a->map_size + 3) / 4) <= kSortPixCells) {
         g.order_img = sb.order_img; g.row_of = sb.row_of;
       }
     }

@@ -42,9 +42,16 @@ def test_piled_up_projections_sort_like_spread_ones(hip, n_points):
     a.sdf = out.data_ptr()
     a.no_activations = 1
     lib = hip.load()
+    plain = hip.sdf_query(dev(q), dev(T), img, vox, packed, precision="fp16", sort_points=False)
+    # the default inference forward samples the map inside fc_0 and sorts by Morton cell only (no pixel order is built)
     assert lib.list_sdf_query_fwd(C.byref(a), hip._stream()) == 0, lib.list_last_error()
     torch.cuda.synchronize()
-    plain = hip.sdf_query(dev(q), dev(T), img, vox, packed, precision="fp16", sort_points=False)
+    assert torch.isfinite(out).all() and torch.equal(out, plain)
+    # the 2-D gather kernel's forward (no_fused_fc0; also every training forward) builds both orders: inspected below
+    out.fill_(float("nan"))
+    a.no_fused_fc0 = 1
+    assert lib.list_sdf_query_fwd(C.byref(a), hip._stream()) == 0, lib.list_last_error()
+    torch.cuda.synchronize()
     assert torch.isfinite(out).all() and torch.equal(out, plain)
     # the orders the call left in its workspace: permutations of the points, inverse of each other where they should be
     ws = keep[-1]
