@@ -134,15 +134,20 @@ def test_config2_full_size(hip, precision):
     assert torch.equal(run_proj(hip, one, precision)[0], sdf[5])
 
 
-def test_config5_full_size_bf16x3(hip):
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16"])
+def test_config5_full_size(hip, precision):
+    """512^2 images, map 274^2, 400 000 points: two row chunks inside one call (the fused + projected fc_0 per chunk in
+    fp16; 2-D gather + row vectors per chunk in bf16x3), query-axis pieces bit for bit."""
     inp = make_inputs(8, 50000, 512, 128, 274, seed=555)
     assert hip.img_proj_kept_levels(inp["img"], 274) == 2
-    sdf = run_proj(hip, inp, "bf16x3")
+    plan = {}
+    sdf = run_proj(hip, inp, precision, plan=plan)
+    assert plan["chunks"] == 2 and plan["img_proj"] == 1
     err, _ = oracle_subset(inp, sdf, 256, seed=12)
-    print(f"config 5 img_proj bf16x3: max-abs err {err:.3e}")
+    print(f"config 5 img_proj {precision}: max-abs err {err:.3e}")
     assert err < 1e-4, err
     half = 25000
-    pieces = torch.cat([run_proj(hip, inp, "bf16x3", inp["query"][:, :half]), run_proj(hip, inp, "bf16x3", inp["query"][:, half:])], 1)
+    pieces = torch.cat([run_proj(hip, inp, precision, inp["query"][:, :half]), run_proj(hip, inp, precision, inp["query"][:, half:])], 1)
     assert torch.equal(pieces, sdf)
 
 
