@@ -183,6 +183,7 @@ def test_module_api_takes_the_projection_for_inference_only(hip, monkeypatch):
     """network/hotpath.sdf_query: inference forwards in the bf16 formats take the projected map (hip.img_proj_default),
     a forward that a backward may follow never does; LIST_IMG_PROJ=0 / 1 forces it."""
     from list_amd.network import hotpath
+    monkeypatch.delenv("LIST_IMG_PROJ", raising=False)            # (the default, whatever the caller's environment says)
     inp, c = case_inputs("small")
     seen = []
     real = hip.sdf_query
