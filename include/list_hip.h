@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LIST_ABI_VERSION 8
+#define LIST_ABI_VERSION 9
 
 #define LIST_N_IMG_LEVELS 5   /* ResEncoder feature maps, network/modules.py:1067 */
 #define LIST_N_VOX_LEVELS 6   /* VoxelEncoder2 feature maps, network/modules.py:425-442 */
@@ -387,13 +387,16 @@ typedef struct ListQueryGradArgs {
                                       /*   the level fits the sort's bins.  Same values up to summation order */
   float* grad_percep_feat;            /* only with fwd->percep_feat (VoxelDecoder2.forward's own form): the    */
   int64_t gpf_sb, gpf_sc, gpf_sn;     /*   gradient of the pre-pooled features, [B,img_C,N] with these strides */
-  void* aux_streams[2];               /* optional: two more hipStream_t of the same device.  The backward is a   */
+  void* aux_streams[3];               /* optional: more hipStream_t of the same device.  The backward is a       */
                                       /*   DAG, not a chain: dW0 (MFMA-bound), the atomic-rate-bound scatters,   */
                                       /*   the LDS-window scatters and the gathers need different units, so they */
                                       /*   are forked onto these streams (event fork/join around them: the call  */
-                                      /*   is still ordered on `stream` as a whole).  NULL: everything in order. */
-                                      /*   [1] carries dW0 and the 16^3 window level, the longest chain: create  */
-                                      /*   it with hipStreamCreateWithPriority(.., -1) (-0.06 ms per step).      */
+                                      /*   is still ordered on `stream` as a whole).  [0] and [1] NULL: all in   */
+                                      /*   order.  [1] carries dW0 and the 16^3 window level, the longest chain: */
+                                      /*   create it with hipStreamCreateWithPriority(.., -1) (-0.06 ms per      */
+                                      /*   step).  [2] (ABI 9, optional beside the other two): the 8^3 window    */
+                                      /*   level, which otherwise waits behind the gathers on `stream` (same     */
+                                      /*   step with the synthetic camera, -0.2 ms with the points on the clamp) */
   const ListMap2D* grad_img_levels;   /* optional: LIST_N_IMG_LEVELS descriptors as list_img_map_grad_to_levels   */
                                       /*   takes them.  The adjoint resize then runs inside this call, beside the */
                                       /*   voxel scatters still in flight on the auxiliary streams (needs         */

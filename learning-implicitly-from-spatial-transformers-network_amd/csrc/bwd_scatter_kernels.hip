@@ -664,9 +664,21 @@ static hipError_t scatter_level(const ScatterParams& sp, const ListVoxLevel& gv,
     if (reach < 0.99f) {
       constexpr int T = C >= 128 ? C : 128;
       if (reach < 0.34f) {          // 8^3: small boxes, four workgroups per CU
+        // fp16, 128 channels: on the matrix cores (k_scatter_vox_box) -- alone 0.28 -> 0.12 ms; beside the other streams of
+        // the forked backward the VALU kernel is the better neighbour (2 waves of 199 registers per workgroup against 4 of
+        // 243: step +0.05 ms with the matrix-core form), so forked calls keep it unless LIST_SCATTER_BOX=2
+        static const int box_mode = [] { const char* e = getenv("LIST_SCATTER_BOX"); return e ? atoi(e) : -1; }();
+        const bool box8 = box_mode < 0 ? !sp.forked : (box_mode == 1 || box_mode == 2);
+        if (box8 && img16 && scatter_box_eligible(sp, gv, col_off, kWinPkScale))
+          return launch_scatter_vox_box(sp, gv, col_off, img16, s);
         if (sp.dx_f16) hipLaunchKernelGGL((k_scatter_vox_win<C, 1, 9216>), grid, dim3(T), 0, s, sp, gv, col_off, img16);
         else hipLaunchKernelGGL((k_scatter_vox_win<C, 0, 9216>), grid, dim3(T), 0, s, sp, gv, col_off, (_Float16*)nullptr);
       } else {
+        // 16^3: the same kernel with runs of <= 128 box rows: alone 0.52 -> 0.24 ms, forked step 6.63 -> 6.29 ms
+        static const int box_mode = [] { const char* e = getenv("LIST_SCATTER_BOX"); return e ? atoi(e) : -1; }();
+        const bool box16 = box_mode < 0 || box_mode == 2 || box_mode == 3;
+        if (box16 && img16 && scatter_box_eligible(sp, gv, col_off, kWinPkScale))
+          return launch_scatter_vox_box(sp, gv, col_off, img16, s);
         if (sp.dx_f16) hipLaunchKernelGGL((k_scatter_vox_win<C, 1, 18432>), grid, dim3(T), 0, s, sp, gv, col_off, img16);
         else hipLaunchKernelGGL((k_scatter_vox_win<C, 0, 18432>), grid, dim3(T), 0, s, sp, gv, col_off, (_Float16*)nullptr);
       }
@@ -699,6 +711,7 @@ hipError_t launch_scatter_vox(const ScatterParams& sp, const FeatLayout& L, cons
                                          (double)sp.g.n_valid * LIST_N_STENCIL >= kVoxGatherMinDensity * (double)n_vox);
     if (vb.bins && dense && n_vox <= kVoxGatherMaxBins && (gv.C == 16 || gv.C == 32 || gv.C == 64 ||
                                                                            gv.C == 128 || gv.C == 256)) {
+      if (bwd_knockout() & 16) continue;
       switch (gv.C) {
         case 16: e = gather_level<16>(sp, gv, L.vox_off[l], B, vb, st.gather); break;
         case 32: e = gather_level<32>(sp, gv, L.vox_off[l], B, vb, st.gather); break;
@@ -709,11 +722,17 @@ hipError_t launch_scatter_vox(const ScatterParams& sp, const FeatLayout& L, cons
       if (e != hipSuccess) return e;
       continue;
     }
-    // the first window level shares its stream with dW0, the second one goes behind the gathers on the caller's stream:
-    // with both behind the (contended) 2-ms dW0 the window stream ended 0.4 ms after the other two (forked backward
-    // 5.16 -> 4.98 ms)
+    if (window_level ? (bwd_knockout() & (n_win_seen == 0 ? 4 : 8)) : (bwd_knockout() & 2)) { if (window_level) ++n_win_seen; continue; }
+    // the first window level shares its stream with dW0; the second one has a stream to itself (st.window2: the
+    // library's own side stream when the backward is forked, else the caller's).  With both behind the (contended) 2-ms
+    // dW0 the window stream ended 0.4 ms after the other two (forked backward 5.16 -> 4.98 ms with the second one behind
+    // the gathers on the caller's stream); on its own stream the training step is the same with the synthetic camera
+    // and 0.17 - 0.22 ms shorter with the points on the clamp, where the gathers ahead of it are the long ones
+    // (profiles/r04b_window_streams_ab.txt, which also has the first level on its own stream: +1.4 ms; with the 16^3 level
+    // on the matrix cores the other orders were measured again -- both levels on window2, the 16^3 level behind the
+    // gathers: +0.08 / +0.4 ms, profiles/r04b_box_adjoint.txt)
     hipStream_t s = st.direct;
-    if (window_level && vb.mode != 2) { s = n_win_seen == 0 ? st.window : st.gather; ++n_win_seen; }
+    if (window_level && vb.mode != 2) { s = n_win_seen == 0 ? st.window : st.window2; ++n_win_seen; }
 #ifndef LIST_BWD_NO_PK_ATOMICS
     // packed-half atomics (see k_scatter_vox_h2): fp16 operands, automatic form choice, C = 32 or a non-window C = 64
     // level, and the level's fp16 image fits the scratch the caller set aside
@@ -1249,7 +1268,7 @@ __global__ __launch_bounds__(256) void k_trans_grad(ScatterParams sp, const void
 hipError_t launch_img_grad(const ScatterParams& sp, const FeatLayout& L, const ListQueryArgs& a,
                            const int* bins_pix, int nslots, void* recs, float* grad_img_map, int map_f16,
                            float* grad_trans_mat, void* const* stage_events, hipStream_t s, void* heavy,
-                           size_t heavy_bytes, hipStream_t s_trans) {
+                           size_t heavy_bytes) {
   (void)nslots;
   const int ms = a.map_size, Ct = L.img_C;
   ImgRec* rc = (ImgRec*)recs;
@@ -1315,8 +1334,7 @@ hipError_t launch_img_grad(const ScatterParams& sp, const FeatLayout& L, const L
   }
   mark(LIST_BWD_IMG);
   if (grad_trans_mat) {
-    // (s_trans: list_capi.hip may place this stage on the direct-atomic levels' stream -- opt-in, see there)
-    hipStream_t st = s_trans ? s_trans : s;
+    hipStream_t st = s;
     const int B = (int)((sp.g.p_begin + sp.g.n_valid + sp.g.N - 1) / sp.g.N);
     hipError_t e = hipMemsetAsync(grad_trans_mat, 0, (size_t)B * 12 * sizeof(float), st);
     if (e != hipSuccess) return e;

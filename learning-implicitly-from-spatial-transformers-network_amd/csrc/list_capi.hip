@@ -946,9 +946,11 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   // a failure after the fork must not leave the auxiliary streams running past the call: the caller frees the
   // workspace and the outputs as soon as it sees the error.  join_and_fail() orders `s` behind whatever has been
   // enqueued on them so far, then reports.
-  hipStream_t j_direct = s, j_window = s;
+  hipStream_t j_direct = s, j_window = s, j_win2 = s;
+  hipEvent_t ev_dw0 = nullptr;                    // dW0 done (forked calls that want d_trans_mat)
   auto join_and_fail = [&](hipError_t err, const char* what) -> int {
-    for (hipStream_t from : {j_direct, j_window}) {
+    if (ev_dw0) { (void)hipEventDestroy(ev_dw0); ev_dw0 = nullptr; }
+    for (hipStream_t from : {j_direct, j_window, j_win2}) {
       if (from == s) continue;
       hipEvent_t ev;
       if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) continue;
@@ -966,10 +968,11 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   auto plane = [&](size_t off) { return (unsigned short*)(bwp + off); };
 
   // optional fork/join onto the caller's auxiliary streams (see ListQueryGradArgs.aux_streams)
-  hipStream_t s_direct = s, s_window = s;
+  hipStream_t s_direct = s, s_window = s, s_win2 = s;
   const bool forked = ga->aux_streams[0] && ga->aux_streams[1];
   if (forked) { s_direct = (hipStream_t)ga->aux_streams[0]; s_window = (hipStream_t)ga->aux_streams[1]; }
-  j_direct = s_direct; j_window = s_window;
+  if (forked && ga->aux_streams[2]) s_win2 = (hipStream_t)ga->aux_streams[2];
+  j_direct = s_direct; j_window = s_window; j_win2 = s_win2;
   auto hand_over = [&](hipStream_t from, hipStream_t to) -> hipError_t {      // `to` continues after `from`'s work so far
     if (from == to) return hipSuccess;
     hipEvent_t ev;
@@ -1008,7 +1011,7 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   vb.h16_bytes = fp16 ? (size_t)rows * a->H1 * 2 : 0;
   vb.h16w = fp16 ? (void*)(bwp + bw.dz2_lo) : nullptr;               // window levels: the dZ2 lo plane
   vb.h16w_bytes = fp16 ? (size_t)rows * a->H2 * 2 : 0;
-  const ScatterStreams sst = {s, s_direct, s_window};
+  const ScatterStreams sst = {s, s_direct, s_window, s_win2};
 
   mark(LIST_BWD_BEGIN);
   // --- head: scale, dZ3, d fc_out (H3 = relu(fc_2) as the forward left it in its workspace) -------------------
@@ -1118,13 +1121,20 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   mark(LIST_BWD_DGRAD0);
 
   // dX is ready on `s`.  From here the work is a DAG of stages bound by different units: dW0 (MFMA; needs only
-  // dZ1 and X) and the LDS-window levels on one stream, the atomic-rate-bound levels on another, the gathers
-  // (voxel-side gather, perceptual map, trans_mat) on `s`.  Without auxiliary streams: the same order, in line.
+  // dZ1 and X) and the 16^3 LDS-window level on one stream, the atomic-rate-bound levels on another, the 8^3 window level
+  // on the third (aux_streams[2]; without it, behind the gathers), the gathers (voxel-side gather, perceptual map,
+  // trans_mat) on `s`.  Without auxiliary streams: the same order, in line.
   LIST_TRY(hand_over(s, s_direct), "stream fork");
   LIST_TRY(hand_over(s, s_window), "stream fork");
+  LIST_TRY(hand_over(s, s_win2), "stream fork");
+  if (!(bwd_knockout() & 1))
   LIST_TRY(wgrad(bw.dz1_hi, bw.dz1_lo, a->H1, fw + ws.x_hi, fw + ws.x_lo, L.Kp, L.Kp, &L, ga->mlp.w0, L.F, s_window),
            "dW0 launch");
   mark(LIST_BWD_WGRAD0);
+  if (forked && ga->grad_trans_mat && !a->percep_feat) {        // (see the trans_mat gradient below)
+    LIST_TRY(hipEventCreateWithFlags(&ev_dw0, hipEventDisableTiming), "event");
+    LIST_TRY(hipEventRecord(ev_dw0, s_window), "event");
+  }
   LIST_TRY(launch_scatter_vox(sp, L, *a, ga->grad_vox, vb, sst), "voxel scatter launch");
   mark(LIST_BWD_VOX);
   if (a->percep_feat) {
@@ -1134,25 +1144,39 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
     mark(LIST_BWD_IMG); mark(LIST_BWD_TRANS);
     LIST_TRY(hand_over(s_direct, s), "stream join");
     LIST_TRY(hand_over(s_window, s), "stream join");
+    LIST_TRY(hand_over(s_win2, s), "stream join");
     return LIST_OK;
   }
   const int nslots = a->B < kSortImages ? a->B : kSortImages;
   const int* bins_pix = pix ? (const int*)(fw + ws.bins) + (size_t)nslots * kSortCells : nullptr;
   if (pix && a->B > kSortImages) { sp.g.order_img = nullptr; sp.g.row_of = nullptr; bins_pix = nullptr; }
   const int map_f16 = ga->grad_img_map_dtype == LIST_MAP_F16 ? 1 : 0;
-  // The trans_mat gradient stays on the caller's stream.  (Round 4: on the direct-atomic levels' stream, idle by then, the
-  // training step ran 6.74 -> 6.66 ms -- and test_backward_large_batch_statistics, which compares backward(2 g) with
-  // 2 backward(g), failed on d_trans_mat by 2.4e-4 whenever the whole GPU suite ran before it (never alone).  No shared
-  // buffer was found by inspection; until the cause is, the placement is opt-in: LIST_BWD_TRANS_SIDE=1.)
-  static const bool trans_inline = [] { const char* e = getenv("LIST_BWD_TRANS_SIDE"); return !(e && e[0] == '1'); }();
-  LIST_TRY(launch_img_grad(sp, L, *a, bins_pix, nslots, bwp + bw.recs, ga->grad_img_map, map_f16, ga->grad_trans_mat,
-                           ga->stage_events, s, bwp + bw.img_heavy, bw.img_heavy_bytes,
-                           (forked && !trans_inline) ? s_direct : s), "image gradient launch");
-  if (ga->grad_img_levels)
-    LIST_TRY(launch_img_grad_to_levels(ga->grad_img_map, a->B, a->map_size, L.img_C, ga->grad_img_levels, s, map_f16,
-                                       scale), "img_grad_to_levels launch");
+  // Forked, k_trans_grad must not run while dW0 does.  Whenever one of its waves shared a SIMD with the weight-gradient
+  // GEMM's (2 x 216 + 80 registers = the whole file in the split formats), ONE point's v-derivative came out different --
+  // d_trans_mat off by 1e-4 .. 7e-3 of its largest entry in 4 - 59 of 60 calls, depending on what else ran (tools/
+  // trans_noise_probe2.py, profiles/r04b_trans_mat_interference.txt: never with dW0 left out, never in line, never once
+  // the kernel held more registers or LDS than fit beside dW0; its inputs, its LDS records and every other gradient
+  // were bit-stable).  The cause below the ISA was not found; the order removes the overlap: map gradient, adjoint
+  // resize (it needs only the map gradient), then -- behind dW0's event -- the trans_mat gradient.  In line the stages
+  // keep their order (and their stage events their meaning).
+  if (!(bwd_knockout() & 32)) {
+    const bool split = forked && ga->grad_trans_mat;
+    LIST_TRY(launch_img_grad(sp, L, *a, bins_pix, nslots, bwp + bw.recs, ga->grad_img_map, map_f16,
+                             split ? nullptr : ga->grad_trans_mat, ga->stage_events, s, bwp + bw.img_heavy,
+                             bw.img_heavy_bytes), "image gradient launch");
+    if (ga->grad_img_levels)
+      LIST_TRY(launch_img_grad_to_levels(ga->grad_img_map, a->B, a->map_size, L.img_C, ga->grad_img_levels, s, map_f16,
+                                         scale), "img_grad_to_levels launch");
+    if (split) {
+      if (ev_dw0) LIST_TRY(hipStreamWaitEvent(s, ev_dw0, 0), "stream order");
+      LIST_TRY(launch_img_grad(sp, L, *a, bins_pix, nslots, bwp + bw.recs, nullptr, map_f16, ga->grad_trans_mat,
+                               ga->stage_events, s, nullptr, 0), "trans_mat gradient launch");
+    }
+  }
+  if (ev_dw0) { (void)hipEventDestroy(ev_dw0); ev_dw0 = nullptr; }
   LIST_TRY(hand_over(s_direct, s), "stream join");
   LIST_TRY(hand_over(s_window, s), "stream join");
+  LIST_TRY(hand_over(s_win2, s), "stream join");
 #undef LIST_TRY
   return LIST_OK;
 }

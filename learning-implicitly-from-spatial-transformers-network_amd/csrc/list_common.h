@@ -548,7 +548,17 @@ constexpr double kVoxGatherMinDensity = LIST_VOX_GATHER_MIN_DENSITY;   // sample
 // levels (packed-half atomics), or null
 struct VoxGatherBuffers { int* keys; int* bins; int* sums; void* recs; int mode; void* h16; size_t h16_bytes; void* h16w; size_t h16w_bytes; };
 // the three adjoint forms may run on different streams (gather / direct atomics / LDS windows)
-struct ScatterStreams { hipStream_t gather, direct, window; };
+// matrix-core adjoint of an 8^3-class level (bwd_box_kernels.hip); pk_scale: the scale of the level's fp16 image
+bool scatter_box_eligible(const ScatterParams& sp, const ListVoxLevel& gv, int col_off, float pk_scale);
+hipError_t launch_scatter_vox_box(const ScatterParams& sp, const ListVoxLevel& gv, int col_off, _Float16* img16,
+                                  hipStream_t s);
+#ifdef LIST_BWD_KNOCKOUT    // diagnostic build (wrong gradients): LIST_BWD_SKIP = bit mask of forked-phase stages left out --
+// 1 dW0, 2 direct-atomic levels, 4 first window level (16^3), 8 second window level (8^3), 16 voxel-side gather, 32 image
+inline int bwd_knockout() { static const int k = [] { const char* e = getenv("LIST_BWD_SKIP"); return e ? atoi(e) : 0; }(); return k; }
+#else
+constexpr int bwd_knockout() { return 0; }
+#endif
+struct ScatterStreams { hipStream_t gather, direct, window, window2; };
 hipError_t launch_scatter_vox(const ScatterParams& sp, const FeatLayout& L, const ListQueryArgs& a,
                               const ListVoxLevel grad_vox[LIST_N_VOX_LEVELS], const VoxGatherBuffers& vb,
                               const ScatterStreams& st);
@@ -558,7 +568,7 @@ hipError_t launch_scatter_vox(const ScatterParams& sp, const FeatLayout& L, cons
 hipError_t launch_img_grad(const ScatterParams& sp, const FeatLayout& L, const ListQueryArgs& a,
                            const int* bins_pix, int nslots, void* recs, float* grad_img_map, int map_f16,
                            float* grad_trans_mat, void* const* stage_events, hipStream_t s, void* heavy = nullptr,
-                           size_t heavy_bytes = 0, hipStream_t s_trans = nullptr);
+                           size_t heavy_bytes = 0);
 hipError_t launch_rows_to_grad(const ScatterParams& sp, int img_off, int C, int B, int* row_of_scratch, float* out,
                                int64_t sb, int64_t sc, int64_t sn, hipStream_t s);
 hipError_t launch_grad_to_rows(const float* src, int64_t sb, int64_t sc, int64_t sn, int B, int N, int C, float* dx,

@@ -88,7 +88,7 @@ class ListQueryGradArgs(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("stage_events", C.POINTER(C.c_void_p)), ("vox_adjoint", C.c_int32),
                 ("grad_percep_feat", C.c_void_p), ("gpf_sb", C.c_int64), ("gpf_sc", C.c_int64),
-                ("gpf_sn", C.c_int64), ("aux_streams", C.c_void_p * 2),
+                ("gpf_sn", C.c_int64), ("aux_streams", C.c_void_p * 3),
                 ("grad_img_levels", C.POINTER(ListMap2D)), ("grad_img_map_dtype", C.c_int32)]
 
 
@@ -176,7 +176,7 @@ _lib = None
 _lock = threading.Lock()
 
 
-ABI_VERSION = 8          # LIST_ABI_VERSION of the include/list_hip.h these ctypes structs mirror (checked in load())
+ABI_VERSION = 9          # LIST_ABI_VERSION of the include/list_hip.h these ctypes structs mirror (checked in load())
 
 
 def load():
@@ -639,7 +639,9 @@ class _AuxStreams:
         if self.pair is None:
             # the second stream carries dW0 and the 16^3 window level, the longest chain of the forked
             # backward: at high priority its workgroups get compute units first (-0.06 ms, measured)
-            self.pair = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device, priority=-1))
+            # (the third one, ABI 9: the 8^3 window level beside the gathers instead of behind them)
+            self.pair = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device, priority=-1),
+                         torch.cuda.Stream(self.device))
         return self.pair
 
     def __exit__(self, *exc):
@@ -724,9 +726,11 @@ def sdf_query_backward(ctx, grad_sdf, packed_bwd, want_mlp=True, want_img=True, 
     if stage_events is not None:
         ga.stage_events = C.cast(stage_events, C.POINTER(C.c_void_p))
     if overlap:        # dW0 | atomic scatters | window scatters | gathers run side by side (joined before return)
-        with _AuxStreams(dev) as (a0, a1), torch.cuda.device(dev):
+        with _AuxStreams(dev) as (a0, a1, a2), torch.cuda.device(dev):
             ga.aux_streams[0], ga.aux_streams[1] = a0.cuda_stream, a1.cuda_stream
-            # The library joins both side streams back into the caller's stream before it returns -- on success AND
+            if os.environ.get("LIST_BWD_WIN2_OWN", "1") != "0":
+                ga.aux_streams[2] = a2.cuda_stream
+            # The library joins the side streams back into the caller's stream before it returns -- on success AND
             # on every error path -- so whatever runs on the caller's stream afterwards (including the caching
             # allocator handing these buffers to a later allocation on that stream) is ordered behind the side
             # work.  No Tensor.record_stream here: it would park the 4 GB of workspace / gradient buffers behind

@@ -60,7 +60,7 @@ STUB(hipError_t launch_grad_scale(const float*, int64_t, int, float*, float*, fl
 STUB(hipError_t launch_head(const float*, const int*, int, int, int, const unsigned short*, const float*, const float*, unsigned short*, unsigned short*, int, hipStream_t), "launch_head")
 STUB(hipError_t launch_colsum(const unsigned short*, const unsigned short*, int, int, int, int, const float*, const int*, const float*, int, float*, float*, hipStream_t), "launch_colsum")
 STUB(hipError_t launch_scatter_vox(const ScatterParams&, const FeatLayout&, const ListQueryArgs&, const ListVoxLevel*, const VoxGatherBuffers&, const ScatterStreams&), "launch_scatter_vox")
-STUB(hipError_t launch_img_grad(const ScatterParams&, const FeatLayout&, const ListQueryArgs&, const int*, int, void*, float*, int, float*, void* const*, hipStream_t, void*, size_t, hipStream_t), "launch_img_grad")
+STUB(hipError_t launch_img_grad(const ScatterParams&, const FeatLayout&, const ListQueryArgs&, const int*, int, void*, float*, int, float*, void* const*, hipStream_t, void*, size_t), "launch_img_grad")
 STUB(hipError_t launch_rows_to_grad(const ScatterParams&, int, int, int, int*, float*, int64_t, int64_t, int64_t, hipStream_t), "launch_rows_to_grad")
 STUB(hipError_t launch_grad_to_rows(const float*, int64_t, int64_t, int64_t, int, int, int, float*, float*, hipStream_t), "launch_grad_to_rows")
 STUB(hipError_t launch_img_grad_to_levels(const float*, int, int, int, const ListMap2D*, hipStream_t, int, const float*), "launch_img_grad_to_levels")

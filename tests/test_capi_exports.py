@@ -36,10 +36,10 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_error_string_without_gpu():
     from list_amd import hip
     lib = hip.load()
-    assert lib.list_abi_version() == 8
+    assert lib.list_abi_version() == 9
     text = open(os.path.join(ROOT, "include", "list_hip.h")).read()
-    assert "#define LIST_ABI_VERSION 8" in text
-    assert hip.ABI_VERSION == 8                      # header, library and ctypes structs move together
+    assert "#define LIST_ABI_VERSION 9" in text
+    assert hip.ABI_VERSION == 9                      # header, library and ctypes structs move together
     # argument validation happens before any HIP call: a NULL args struct is rejected cleanly
     assert lib.list_sdf_query_fwd(None, None) == -1
     assert b"NULL" in lib.list_last_error()
@@ -92,7 +92,7 @@ def test_binding_refuses_a_library_of_another_abi_version(monkeypatch):
     hip.load()                                       # the real pair agrees
     monkeypatch.setattr(hip, "_lib", None)           # force a fresh load against a binding that claims another version
     monkeypatch.setattr(hip, "ABI_VERSION", hip.ABI_VERSION - 1)
-    with pytest.raises(RuntimeError, match="speaks ABI 8, this binding ABI 7"):
+    with pytest.raises(RuntimeError, match="speaks ABI 9, this binding ABI 8"):
         hip.load()
     assert hip._lib is None                          # nothing half-loaded is left behind
 

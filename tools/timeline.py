@@ -45,7 +45,7 @@ def main():
         tot = sum(int(rows[j]["End_Timestamp"]) - int(rows[j]["Start_Timestamp"]) for j in range(a + 1, b))
         print(f"== forked phase behind dX: {b - a - 1} kernels, span {span / 1e6:.3f} ms, sum of their durations {tot / 1e6:.3f} ms, "
               f"sum / span = {tot / span:.2f}")
-        for pat in ("k_gemm_tn", "k_scatter_vox<16", "k_scatter_vox_h2", "k_scatter_vox1", "k_vs_gather", "k_scatter_vox_win",
+        for pat in ("k_gemm_tn", "k_scatter_vox<16", "k_scatter_vox_h2", "k_scatter_vox1", "k_vs_gather", "k_scatter_vox_win", "k_scatter_vox_box",
                     "k_img_grad_gather", "k_trans_grad", "k_img_grad_level"):
             ds = [(int(rows[j]["End_Timestamp"]) - int(rows[j]["Start_Timestamp"])) / 1e3 for j in range(a + 1, b) if names[j].startswith(pat)]
             if ds:
