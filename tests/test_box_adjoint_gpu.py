@@ -1,26 +1,29 @@
 """GPU: the matrix-core adjoint of the coarse voxel levels (k_scatter_vox_box, csrc/bwd_box_kernels.hip; the reference's autograd of
 network/modules.py:256-265 for the 16^3 and 8^3 x 128-channel levels, fp16 operands) against the LDS-window kernel it replaces.
 
-Both consume the SAME dX (everything before the voxel adjoint is deterministic) and flush packed halfs into the same fp16 image,
-so they differ by the order of the fp32 sums and by where the sums are cut into flushes (each flush rounded to 11 bits): 1e-3 of
-a level's largest entry, against O(1) for any error in a tap, a weight or a run's box.  The library reads LIST_SCATTER_BOX once,
-so the window kernel's gradients come from a second process (this file run as a script)."""
+Both consume the SAME dX (everything before the voxel adjoint is deterministic) and flush packed halfs into the same fp16 image, so they
+differ by the order of the fp32 sums inside a run and by how the sums are cut into flushes; every flush-add rounds the voxel's running
+sum to 11 bits, and a voxel of these levels receives tens of flushes: two runs of the SAME kernel differ by 1 - 2e-3 of a level's largest
+entry (measured; the order of the atomics), so the bound is 6e-3 (3e-3 in L2) -- against O(0.1 .. 1) for any error in a tap, a weight or
+a run's box.  (The packed-half flush, hence the matrix-core kernel, needs the level's fp16 image to fit the call's scratch: at least
+4 096 rows per image, so there is no few-points form of this test.)  The library reads LIST_SCATTER_BOX once per process, so each side
+comes from a process of its own (this file run as a script): 0 = window kernels, 2 = matrix-core kernel on both levels."""
 import os
 import subprocess
 import sys
 
 import numpy as np
 import pytest
-import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
 WANT = dict(want_mlp=False, want_img=False, want_trans=False)
+CASES = {"one_image": dict(seed=8181, batch=1, n=6000), "two_images": dict(seed=8282, batch=2, n=9000)}
 
 
-def coarse_level_gradients(overlap, precision="fp16", seed=8181, batch=2, n=3000):
+def coarse_level_gradients(case, overlap, precision="fp16"):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import __graft_entry__ as ge
     ge.build()
@@ -28,45 +31,58 @@ def coarse_level_gradients(overlap, precision="fp16", seed=8181, batch=2, n=3000
     from oracle import cases, synth
     from test_hip_backward import hip_gradients
     hip.load()
-    c = cases._case(seed=seed, batch=batch, n=n, img_res=64, vox_res=128)      # levels 4, 5: 16^3 and 8^3 x 128 channels
-    gs = synth.normalish(seed + 1, (batch, n))
+    k = CASES[case]
+    c = cases._case(seed=k["seed"], batch=k["batch"], n=k["n"], img_res=64, vox_res=128)   # levels 4, 5: 16^3 and 8^3 x 128 channels
+    gs = synth.normalish(k["seed"] + 1, (k["batch"], k["n"]))
     _, g = hip_gradients(hip, c, gs, precision, want=dict(WANT, overlap=overlap))
-    return {k: g[k] for k in ("d_vox3", "d_vox4", "d_vox5")}
+    return {k2: g[k2] for k2 in ("d_vox3", "d_vox4", "d_vox5")}
 
 
 def rel_max(a, ref):
     return float(np.abs(a - ref).max() / (np.abs(ref).max() + 1e-30))
 
 
-@pytest.fixture(scope="module")
-def window_kernel_gradients(tmp_path_factory):
-    out = str(tmp_path_factory.mktemp("boxadj") / "window.npz")
-    env = dict(os.environ, LIST_SCATTER_BOX="0", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), out], env=env, capture_output=True, text=True, timeout=600)
+def other_process(tmp, mode, case, overlap):
+    out = os.path.join(tmp, f"{case}_{mode}_{int(overlap)}.npz")
+    env = dict(os.environ, LIST_SCATTER_BOX=str(mode), PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), out, case, str(int(overlap))], env=env, capture_output=True,
+                       text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     return dict(np.load(out))
 
 
+def test_the_fp16_images_of_both_levels_fit_the_scratch_in_these_cases():
+    """(What makes a window level take the packed-half flush, hence the matrix-core kernel: bwd_scatter_kernels.hip,
+    launch_scatter_vox -- two window levels share rows x H2 halfs of scratch.)"""
+    for k in CASES.values():
+        rows = (k["batch"] * k["n"] + 255) // 256 * 256
+        slot = rows * 256 * 2 // 2 // 256 * 256
+        assert k["batch"] * 16 ** 3 * 128 * 2 <= slot
+        assert k["batch"] * 8 ** 3 * 128 * 2 <= slot
+
+
+@pytest.mark.parametrize("case,bound", [("one_image", 6e-3), ("two_images", 6e-3)])
 @pytest.mark.parametrize("overlap", [False, True])
-def test_matrix_core_adjoint_equals_the_window_kernel_up_to_flush_rounding(window_kernel_gradients, overlap):
-    """overlap=False: both coarse levels take the matrix-core kernel; overlap=True (forked backward): the 16^3 level does."""
-    assert torch.cuda.is_available()
-    got = coarse_level_gradients(overlap)
-    ref = window_kernel_gradients
+def test_matrix_core_adjoint_equals_the_window_kernel_up_to_flush_rounding(tmp_path, case, bound, overlap):
+    win = other_process(str(tmp_path), 0, case, overlap)
+    box = other_process(str(tmp_path), 2, case, overlap)
     for k in ("d_vox4", "d_vox5"):
-        assert np.isfinite(got[k]).all(), k
-        assert np.abs(ref[k]).max() > 0
-        assert rel_max(got[k], ref[k]) < 2e-3, (k, rel_max(got[k], ref[k]))
-    assert not np.array_equal(got["d_vox4"], ref["d_vox4"])            # the other kernel did run
-    if not overlap:
-        assert not np.array_equal(got["d_vox5"], ref["d_vox5"])
-    assert rel_max(got["d_vox3"], ref["d_vox3"]) < 2e-3                 # (64 channels: the window kernel either way)
+        assert np.isfinite(box[k]).all(), k
+        assert np.abs(win[k]).max() > 0
+        assert rel_max(box[k], win[k]) < bound, (k, rel_max(box[k], win[k]))
+        l2 = float(np.linalg.norm((box[k] - win[k]).ravel()) / np.linalg.norm(win[k].ravel()))
+        assert l2 < bound / 2, (k, l2)
+    assert rel_max(box["d_vox3"], win["d_vox3"]) < bound               # (64 channels: the window kernel either way)
+    # ... and the library's default choice in THIS process (16^3 level on the matrix cores; 8^3 too when not forked)
+    got = coarse_level_gradients(case, overlap)
+    for k in ("d_vox4", "d_vox5"):
+        assert rel_max(got[k], win[k]) < bound, (k, rel_max(got[k], win[k]))
 
 
 def test_matrix_core_adjoint_against_the_fp32_grade_backward():
     """... and against the bf16x3 backward (fp32 atomics, fp32-grade dX): the fp16 mode's stated L2 bound (tests/test_hip_backward.py)."""
-    got = coarse_level_gradients(False)
-    ref = coarse_level_gradients(False, precision="bf16x3")
+    got = coarse_level_gradients("one_image", False)
+    ref = coarse_level_gradients("one_image", False, precision="bf16x3")
     for k in ("d_vox4", "d_vox5"):
         err = float(np.linalg.norm((got[k] - ref[k]).ravel()) / np.linalg.norm(ref[k].ravel()))
         assert err < 0.08, (k, err)
@@ -74,4 +90,4 @@ def test_matrix_core_adjoint_against_the_fp32_grade_backward():
 
 if __name__ == "__main__":
     sys.path.insert(0, ROOT)
-    np.savez(sys.argv[1], **coarse_level_gradients(False))
+    np.savez(sys.argv[1], **coarse_level_gradients(sys.argv[2], bool(int(sys.argv[3]))))
