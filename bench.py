@@ -442,9 +442,9 @@ def run_train_step(precision, steps, warmup, inp, hip, ev):
             "forward_query_ms": fwd_ms / steps, "backward_ms": bwd_ms / steps,
             "kernel_ms": kernel_ms,
             "kernel_ms_note": "stage intervals on the main stream; dW0, the atomic and the LDS-window voxel levels "
-                              "run concurrently on two auxiliary streams and the adjoint resize to the 5 encoder "
-                              "levels follows trans_mat_grad on the main stream inside the same call, so the stages "
-                              "overlap and do not add up to backward_ms",
+                              "run concurrently on three auxiliary streams; on the main stream the adjoint resize to the 5 "
+                              "encoder levels runs between the map gradient and trans_mat_grad (which waits for dW0) "
+                              "inside the same call, so the stages overlap and do not add up to backward_ms",
             "outputs": "d fc_0..fc_out (reference layout), d 5 image maps, d 6 voxel maps, d trans_mat"}, grads
 
 
