@@ -19,10 +19,12 @@
 // Workgroup = 64 consecutive rows (Morton order), 256 threads; runs = the forward's aligned power-of-two runs whose box
 // has at most 128 rows (a single point's 4 x 4 x 4 always fits; at 16^3 that is ~8 points per run).
 //
-// Measured (config 2, 160 000 points, in-line backward, rocprofv3 kernel trace): 16^3 level 0.519 -> 0.239 ms, 8^3 level
-// 0.28 -> 0.118 ms against k_scatter_vox_win; of the 0.239 ms the flush is 0.085 (exposed), the K loop 0.114 -- the weights
-// on the VALU more than the 32 MFMAs of a K-step: hi-only weights save 0.02 --, and 0.08 is what reading 287 MB of dX, the
-// point records and the partition take (profiles/r04b_box_adjoint.txt).  fp16 training step: 6.63 -> 6.29 ms.
+// Measured (config 2, 160 000 points, in-line backward, rocprofv3 kernel trace): 16^3 level 0.519 -> 0.224 ms, 8^3 level
+// 0.28 -> 0.118 ms against k_scatter_vox_win; of the 0.239 ms it took before its row -> voxel divisions became multiply-shifts
+// (0.224 now) the flush was 0.085 (exposed), the K loop 0.114 -- the weights
+// on the VALU more than the 32 MFMAs of a K-step: hi-only weights save 0.02; the per-axis factors read from per-point
+// LDS tables instead of compared and selected per lane: 0.224 -> 0.231 ms, dropped --, and 0.08 is what reading 287 MB of
+// dX, the point records and the partition take (profiles/r04b_box_adjoint.txt).  fp16 training step: 6.63 -> 6.29 ms.
 #include "list_common.h"
 #include "point_math.h"
 #include "box_partition.h"
@@ -140,13 +142,14 @@ __global__ __launch_bounds__(256, 2) void k_scatter_vox_box(ScatterParams sp, Li
     const int rows = nx * ny * nz;
     if (rows == 0) { first += count; continue; }                // no valid point in the run (uniform)
     const int n_vt = (rows + 15) >> 4;                          // box-row tiles in use
+    const int inv_nx = (65536 + nx - 1) / nx, inv_ny = (65536 + ny - 1) / ny;
     // this lane's box rows (tiles wave, wave + 4) as absolute voxel coordinates; a row beyond the box matches nothing
     int vx[2], vy[2], vz[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int v = 16 * (wave + 4 * i) + col;
-      const int yz = v / nx, ix = v - yz * nx;
-      const int iz = yz / ny, iy = yz - iz * ny;
+      const int yz = (v * inv_nx) >> 16, ix = v - yz * nx;
+      const int iz = (yz * inv_ny) >> 16, iy = yz - iz * ny;
       const bool in = v < rows;
       vx[i] = in ? lox + ix : -4; vy[i] = in ? loy + iy : -4; vz[i] = in ? loz + iz : -4;
     }
@@ -281,14 +284,15 @@ __global__ __launch_bounds__(256, 2) void k_scatter_vox_box(ScatterParams sp, Li
     {
       typedef _Float16 half2v __attribute__((ext_vector_type(2)));
       _Float16* base16 = img16 + (int64_t)rb_b * gv.image_stride;
-      for (int i = tid; i < rows * (kAdjC / 2); i += 256) {
-        const int v = i >> 6, cp = i & 63;                       // channel pair cp = channels 2 cp, 2 cp + 1
-        const unsigned bits = *(const unsigned*)(smem + L::stage + v * RB + ((((cp >> 2) ^ (v & 15)) << 4) | ((cp & 3) << 2)));
+      // one box row per wave and pass (its voxel address is scalar arithmetic), lane = channel pair 2 lane, 2 lane + 1
+#pragma unroll 1
+      for (int v = wave; v < rows; v += 4) {
+        const int yz = (v * inv_nx) >> 16, ix = v - yz * nx;           // (exact for v < 256: the forward's box copy)
+        const int iz = (yz * inv_ny) >> 16, iy = yz - iz * ny;
+        const unsigned bits = *(const unsigned*)(smem + L::stage + v * RB + ((((lane >> 2) ^ (v & 15)) << 4) | ((lane & 3) << 2)));
         if ((bits & 0x7fff7fffu) == 0u) continue;
-        const int yz = v / nx, ix = v - yz * nx;
-        const int iz = yz / ny, iy = yz - iz * ny;
         __builtin_amdgcn_global_atomic_fadd_v2f16(
-            (__attribute__((address_space(1))) half2v*)(base16 + ((int64_t)((loz + iz) * H + (loy + iy)) * W + (lox + ix)) * kAdjC + 2 * cp),
+            (__attribute__((address_space(1))) half2v*)(base16 + ((int64_t)((loz + iz) * H + (loy + iy)) * W + (lox + ix)) * kAdjC + 2 * lane),
             __builtin_bit_cast(half2v, bits));
       }
     }
