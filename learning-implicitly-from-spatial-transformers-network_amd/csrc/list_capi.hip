@@ -1173,6 +1173,7 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
                                ga->stage_events, s, nullptr, 0), "trans_mat gradient launch");
     }
   }
+  if (bwd_knockout() & 32) { mark(LIST_BWD_IMG); mark(LIST_BWD_TRANS); }
   if (ev_dw0) { (void)hipEventDestroy(ev_dw0); ev_dw0 = nullptr; }
   LIST_TRY(hand_over(s_direct, s), "stream join");
   LIST_TRY(hand_over(s_window, s), "stream join");
