@@ -52,7 +52,10 @@ struct AdjLds {
 static_assert(2 * AdjLds::stage_bytes <= AdjLds::region, "the two staging buffers share the box's LDS");
 
 // grid = rows / 64, block = 256.  img16: the level's zeroed fp16 image (gradient scale x kAdjPkScale).
+// F32OUT (diagnostic, LIST_SCATTER_F32=1): the accumulators go straight to the level's zeroed fp32 gradient as float
+// atomics, unrounded -- the form tests/test_box_adjoint_gpu.py compares with the window kernel's fp32 flush at 2e-5.
 // (243 registers, two workgroups per CU; held to 168 for three the compiler spills 300 B and the kernel takes 2.2x as long)
+template <int F32OUT>
 __global__ __launch_bounds__(256, 2) void k_scatter_vox_box(ScatterParams sp, ListVoxLevel gv, int col_off,
                                                           _Float16* __restrict__ img16) {
   using L = AdjLds;
@@ -261,6 +264,30 @@ __global__ __launch_bounds__(256, 2) void k_scatter_vox_box(ScatterParams sp, Li
         }
       }
     }
+    if (F32OUT) {
+      // D: column = box row (lane & 15), rows 4 q + reg of tile t = channels 32 (t >> 1) + 8 q + 4 (t & 1) + reg
+      const float inv_s = sp.scale[1];
+      float* base = (float*)gv.data + (int64_t)rb_b * gv.image_stride;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (i == 0 ? !own0 : !own1) continue;
+        const int v = 16 * (wave + 4 * i) + col;
+        if (v >= rows) continue;
+        const int yz = (v * inv_nx) >> 16, ix = v - yz * nx;
+        const int iz = (yz * inv_ny) >> 16, iy = yz - iz * ny;
+        float* dst = base + ((int64_t)((loz + iz) * H + (loy + iy)) * W + (lox + ix)) * kAdjC;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float val = acc[i][t][e];
+            if (val != 0.f) atomicAdd(dst + 32 * (t >> 1) + 8 * q + 4 * (t & 1) + e, val * inv_s);
+          }
+      }
+      first += count;
+      if (first < kAdjPts) __syncthreads();                     // the next run stages over the buffers
+      continue;
+    }
     __syncthreads();                   // every wave is done with the staging buffers: the box takes their place
     // D: column = box row (lane & 15), rows 4 q + reg of tile t = channels 32 (t >> 1) + 8 q + 4 (t & 1) + reg -> 16-B
     // pieces of 8 consecutive channels, chunk XOR (row & 15) (the 16 rows of a tile land on distinct banks)
@@ -302,6 +329,11 @@ __global__ __launch_bounds__(256, 2) void k_scatter_vox_box(ScatterParams sp, Li
 }
 
 // a window level (stencil shorter than a voxel), fp16 dX, 128 channels, image scaled by `pk_scale`
+bool scatter_f32_diagnostic() {
+  static const bool on = [] { const char* e = getenv("LIST_SCATTER_F32"); return e && e[0] == '1'; }();
+  return on;
+}
+
 bool scatter_box_eligible(const ScatterParams& sp, const ListVoxLevel& gv, int col_off, float pk_scale) {
   static const bool off = [] { const char* e = getenv("LIST_SCATTER_BOX"); return e && e[0] == '0' && e[1] == 0; }();
   if (off || !sp.dx_f16 || gv.C != kAdjC || pk_scale != kAdjPkScale) return false;
@@ -312,7 +344,8 @@ bool scatter_box_eligible(const ScatterParams& sp, const ListVoxLevel& gv, int c
 
 hipError_t launch_scatter_vox_box(const ScatterParams& sp, const ListVoxLevel& gv, int col_off, _Float16* img16,
                                   hipStream_t s) {
-  hipLaunchKernelGGL(k_scatter_vox_box, dim3((unsigned)(sp.g.rows / kAdjPts)), dim3(256), 0, s, sp, gv, col_off, img16);
+  if (img16) hipLaunchKernelGGL(k_scatter_vox_box<0>, dim3((unsigned)(sp.g.rows / kAdjPts)), dim3(256), 0, s, sp, gv, col_off, img16);
+  else hipLaunchKernelGGL(k_scatter_vox_box<1>, dim3((unsigned)(sp.g.rows / kAdjPts)), dim3(256), 0, s, sp, gv, col_off, img16);
   return hipGetLastError();
 }
 

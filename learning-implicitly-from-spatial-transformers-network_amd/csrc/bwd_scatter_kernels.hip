@@ -669,7 +669,7 @@ static hipError_t scatter_level(const ScatterParams& sp, const ListVoxLevel& gv,
         // 243: step +0.05 ms with the matrix-core form), so forked calls keep it unless LIST_SCATTER_BOX=2
         static const int box_mode = [] { const char* e = getenv("LIST_SCATTER_BOX"); return e ? atoi(e) : -1; }();
         const bool box8 = box_mode < 0 ? !sp.forked : (box_mode == 1 || box_mode == 2);
-        if (box8 && img16 && scatter_box_eligible(sp, gv, col_off, kWinPkScale))
+        if (box8 && (img16 || scatter_f32_diagnostic()) && scatter_box_eligible(sp, gv, col_off, kWinPkScale))
           return launch_scatter_vox_box(sp, gv, col_off, img16, s);
         if (sp.dx_f16) hipLaunchKernelGGL((k_scatter_vox_win<C, 1, 9216>), grid, dim3(T), 0, s, sp, gv, col_off, img16);
         else hipLaunchKernelGGL((k_scatter_vox_win<C, 0, 9216>), grid, dim3(T), 0, s, sp, gv, col_off, (_Float16*)nullptr);
@@ -677,7 +677,7 @@ static hipError_t scatter_level(const ScatterParams& sp, const ListVoxLevel& gv,
         // 16^3: the same kernel with runs of <= 128 box rows: alone 0.52 -> 0.24 ms, forked step 6.63 -> 6.29 ms
         static const int box_mode = [] { const char* e = getenv("LIST_SCATTER_BOX"); return e ? atoi(e) : -1; }();
         const bool box16 = box_mode < 0 || box_mode == 2 || box_mode == 3;
-        if (box16 && img16 && scatter_box_eligible(sp, gv, col_off, kWinPkScale))
+        if (box16 && (img16 || scatter_f32_diagnostic()) && scatter_box_eligible(sp, gv, col_off, kWinPkScale))
           return launch_scatter_vox_box(sp, gv, col_off, img16, s);
         if (sp.dx_f16) hipLaunchKernelGGL((k_scatter_vox_win<C, 1, 18432>), grid, dim3(T), 0, s, sp, gv, col_off, img16);
         else hipLaunchKernelGGL((k_scatter_vox_win<C, 0, 18432>), grid, dim3(T), 0, s, sp, gv, col_off, (_Float16*)nullptr);
@@ -762,7 +762,7 @@ hipError_t launch_scatter_vox(const ScatterParams& sp, const FeatLayout& L, cons
 #ifndef LIST_BWD_NO_PK_ATOMICS
     // window levels, fp16 operands: packed-half flush into the level's fp16 image (its own scratch slot: the window
     // levels run beside the direct ones), then one pass to fp32
-    if (window_level && sp.dx_f16 && vb.mode == 0 && (gv.C == 64 || gv.C == 128 || gv.C == 256) && vb.h16w) {
+    if (window_level && sp.dx_f16 && vb.mode == 0 && (gv.C == 64 || gv.C == 128 || gv.C == 256) && vb.h16w && !scatter_f32_diagnostic()) {
       const size_t n_elem = (size_t)B * gv.image_stride;
       const size_t slot = vb.h16w_bytes / 2 / 256 * 256;         // two window levels at most share the scratch
       char* img = (char*)vb.h16w + (size_t)(n_win_pk & 1) * slot;

@@ -550,6 +550,7 @@ struct VoxGatherBuffers { int* keys; int* bins; int* sums; void* recs; int mode;
 // the three adjoint forms may run on different streams (gather / direct atomics / LDS windows)
 // matrix-core adjoint of an 8^3-class level (bwd_box_kernels.hip); pk_scale: the scale of the level's fp16 image
 bool scatter_box_eligible(const ScatterParams& sp, const ListVoxLevel& gv, int col_off, float pk_scale);
+bool scatter_f32_diagnostic();      // LIST_SCATTER_F32=1: the window levels flush fp32 atomics (both kernels; tests)
 hipError_t launch_scatter_vox_box(const ScatterParams& sp, const ListVoxLevel& gv, int col_off, _Float16* img16,
                                   hipStream_t s);
 #ifdef LIST_BWD_KNOCKOUT    // diagnostic build (wrong gradients): LIST_BWD_SKIP = bit mask of forked-phase stages left out --

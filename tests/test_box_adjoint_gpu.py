@@ -7,7 +7,8 @@ sum to 11 bits, and a voxel of these levels receives tens of flushes: two runs o
 entry (measured; the order of the atomics), so the bound is 6e-3 (3e-3 in L2) -- against O(0.1 .. 1) for any error in a tap, a weight or
 a run's box.  (The packed-half flush, hence the matrix-core kernel, needs the level's fp16 image to fit the call's scratch: at least
 4 096 rows per image, so there is no few-points form of this test.)  The library reads LIST_SCATTER_BOX once per process, so each side
-comes from a process of its own (this file run as a script): 0 = window kernels, 2 = matrix-core kernel on both levels."""
+comes from a process of its own (this file run as a script): 0 = window kernels, 2 = matrix-core kernel on both levels.  The sharp
+comparison is the fp32-flush form below."""
 import os
 import subprocess
 import sys
@@ -42,9 +43,10 @@ def rel_max(a, ref):
     return float(np.abs(a - ref).max() / (np.abs(ref).max() + 1e-30))
 
 
-def other_process(tmp, mode, case, overlap):
-    out = os.path.join(tmp, f"{case}_{mode}_{int(overlap)}.npz")
-    env = dict(os.environ, LIST_SCATTER_BOX=str(mode), PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+def other_process(tmp, mode, case, overlap, f32=False):
+    out = os.path.join(tmp, f"{case}_{mode}_{int(overlap)}_{int(f32)}.npz")
+    env = dict(os.environ, LIST_SCATTER_BOX=str(mode), LIST_SCATTER_F32="1" if f32 else "0",
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     r = subprocess.run([sys.executable, os.path.abspath(__file__), out, case, str(int(overlap))], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -77,6 +79,18 @@ def test_matrix_core_adjoint_equals_the_window_kernel_up_to_flush_rounding(tmp_p
     got = coarse_level_gradients(case, overlap)
     for k in ("d_vox4", "d_vox5"):
         assert rel_max(got[k], win[k]) < bound, (k, rel_max(got[k], win[k]))
+
+
+@pytest.mark.parametrize("case", ["one_image", "two_images"])
+def test_matrix_core_adjoint_equals_the_window_kernel_when_both_flush_fp32(tmp_path, case):
+    """The sharp form: LIST_SCATTER_F32=1 (diagnostic) makes both kernels add their UNROUNDED fp32 sums into the fp32 gradient, so
+    what is left between them is the order of fp32 additions -- 5e-7 of a level's largest entry, where a wrong tap, weight, slot or
+    box row would show at 1e-2 .. 1.  (The shipped packed-half flush rounds the same accumulators.)"""
+    win = other_process(str(tmp_path), 0, case, False, f32=True)
+    box = other_process(str(tmp_path), 2, case, False, f32=True)
+    for k in ("d_vox4", "d_vox5"):
+        assert np.abs(win[k]).max() > 0
+        assert rel_max(box[k], win[k]) < 5e-6, (k, rel_max(box[k], win[k]))     # measured 3 - 5e-7 (the window kernel twice: 2 - 3e-7)
 
 
 def test_matrix_core_adjoint_against_the_fp32_grade_backward():
