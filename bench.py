@@ -433,7 +433,7 @@ def run_train_step(precision, steps, warmup, inp, hip, ev):
                                 "direct_levels_atomic_bytes": direct,
                                 "achieved_lower_bound": direct / (inline_ms["scatter_vox"] * 1e-3) / 1e9,
                                 "frac_lower_bound": direct / (inline_ms["scatter_vox"] * 1e-3) / 1e9 / PEAK_ATOMIC_GBS,
-                                "note": "the stage also holds the two LDS-window levels (flush atomics, data dependent) "
+                                "note": "the stage also holds the two coarse levels (matrix-core adjoint, fp16: flush atomics, data dependent) "
                                         "and the voxel-side gather of the 32^3 level: the fraction is a lower bound"}}
     assert 0.0 < roofline["frac"] <= 1.0
     return {"precision": precision, "steps": steps, "ms_per_step": elapsed / steps * 1e3,
