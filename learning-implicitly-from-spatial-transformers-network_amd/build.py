@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(CSRC, "liblist_hip.so")
 SOURCES = ["prep_kernels.hip", "gather_kernels.hip", "gather_box_kernels.hip", "gemm_kernels.hip", "fused_fc0_kernels.hip", "bwd_mlp_kernels.hip",
-           "bwd_scatter_kernels.hip", "bwd_box_kernels.hip", "list_capi.hip"]
+           "bwd_scatter_kernels.hip", "bwd_box_kernels.hip", "bwd_box_split_kernels.hip", "list_capi.hip"]
 HEADERS = ["list_common.h", "point_math.h", "gather_math.h", "mfma_common.h", "box_partition.h"]
 OBJ_DIR = os.path.join(CSRC, "_obj")
 ARCH = "gfx950"

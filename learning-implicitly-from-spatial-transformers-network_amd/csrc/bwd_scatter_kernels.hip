@@ -671,6 +671,8 @@ static hipError_t scatter_level(const ScatterParams& sp, const ListVoxLevel& gv,
         const bool box8 = box_mode < 0 ? !sp.forked : (box_mode == 1 || box_mode == 2);
         if (box8 && (img16 || scatter_f32_diagnostic()) && scatter_box_eligible(sp, gv, col_off, kWinPkScale))
           return launch_scatter_vox_box(sp, gv, col_off, img16, s);
+        if (box8 && !img16 && scatter_box_split_eligible(sp, gv, col_off))       // fp32 dX (bf16x3, bf16): bf16 hi + lo operands
+          return launch_scatter_vox_box_split(sp, gv, col_off, s);
         if (sp.dx_f16) hipLaunchKernelGGL((k_scatter_vox_win<C, 1, 9216>), grid, dim3(T), 0, s, sp, gv, col_off, img16);
         else hipLaunchKernelGGL((k_scatter_vox_win<C, 0, 9216>), grid, dim3(T), 0, s, sp, gv, col_off, (_Float16*)nullptr);
       } else {
@@ -679,6 +681,8 @@ static hipError_t scatter_level(const ScatterParams& sp, const ListVoxLevel& gv,
         const bool box16 = box_mode < 0 || box_mode == 2 || box_mode == 3;
         if (box16 && (img16 || scatter_f32_diagnostic()) && scatter_box_eligible(sp, gv, col_off, kWinPkScale))
           return launch_scatter_vox_box(sp, gv, col_off, img16, s);
+        if (box16 && !img16 && scatter_box_split_eligible(sp, gv, col_off))
+          return launch_scatter_vox_box_split(sp, gv, col_off, s);
         if (sp.dx_f16) hipLaunchKernelGGL((k_scatter_vox_win<C, 1, 18432>), grid, dim3(T), 0, s, sp, gv, col_off, img16);
         else hipLaunchKernelGGL((k_scatter_vox_win<C, 0, 18432>), grid, dim3(T), 0, s, sp, gv, col_off, (_Float16*)nullptr);
       }

@@ -550,6 +550,9 @@ struct VoxGatherBuffers { int* keys; int* bins; int* sums; void* recs; int mode;
 // the three adjoint forms may run on different streams (gather / direct atomics / LDS windows)
 // matrix-core adjoint of an 8^3-class level (bwd_box_kernels.hip); pk_scale: the scale of the level's fp16 image
 bool scatter_box_eligible(const ScatterParams& sp, const ListVoxLevel& gv, int col_off, float pk_scale);
+// ... and for the formats whose dX is fp32 (bwd_box_split_kernels.hip: bf16 hi + lo operands, fp32 flush)
+bool scatter_box_split_eligible(const ScatterParams& sp, const ListVoxLevel& gv, int col_off);
+hipError_t launch_scatter_vox_box_split(const ScatterParams& sp, const ListVoxLevel& gv, int col_off, hipStream_t s);
 bool scatter_f32_diagnostic();      // LIST_SCATTER_F32=1: the window levels flush fp32 atomics (both kernels; tests)
 hipError_t launch_scatter_vox_box(const ScatterParams& sp, const ListVoxLevel& gv, int col_off, _Float16* img16,
                                   hipStream_t s);

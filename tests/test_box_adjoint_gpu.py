@@ -1,4 +1,4 @@
-"""GPU: the matrix-core adjoint of the coarse voxel levels (k_scatter_vox_box, csrc/bwd_box_kernels.hip; the reference's autograd of
+"""GPU: the matrix-core adjoint of the coarse voxel levels (k_scatter_vox_box / k_scatter_vox_box_split, csrc/bwd_box*_kernels.hip; the reference's autograd of
 network/modules.py:256-265 for the 16^3 and 8^3 x 128-channel levels, fp16 operands) against the LDS-window kernel it replaces.
 
 Both consume the SAME dX (everything before the voxel adjoint is deterministic) and flush packed halfs into the same fp16 image, so they
@@ -43,12 +43,12 @@ def rel_max(a, ref):
     return float(np.abs(a - ref).max() / (np.abs(ref).max() + 1e-30))
 
 
-def other_process(tmp, mode, case, overlap, f32=False):
-    out = os.path.join(tmp, f"{case}_{mode}_{int(overlap)}_{int(f32)}.npz")
+def other_process(tmp, mode, case, overlap, f32=False, precision="fp16"):
+    out = os.path.join(tmp, f"{case}_{mode}_{int(overlap)}_{int(f32)}_{precision}.npz")
     env = dict(os.environ, LIST_SCATTER_BOX=str(mode), LIST_SCATTER_F32="1" if f32 else "0",
                PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), out, case, str(int(overlap))], env=env, capture_output=True,
-                       text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), out, case, str(int(overlap)), precision], env=env,
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     return dict(np.load(out))
 
@@ -93,6 +93,22 @@ def test_matrix_core_adjoint_equals_the_window_kernel_when_both_flush_fp32(tmp_p
         assert rel_max(box[k], win[k]) < 5e-6, (k, rel_max(box[k], win[k]))     # measured 3 - 5e-7 (the window kernel twice: 2 - 3e-7)
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_split_operand_adjoint_equals_the_window_kernel_to_its_products_grade(tmp_path, precision):
+    """The formats whose dX is fp32 (k_scatter_vox_box_split, bwd_box_split_kernels.hip): both kernels add fp32 sums into the fp32
+    gradient; the window kernel multiplies in fp32, the matrix-core kernel takes bf16 hi + lo of both operands (three products,
+    16 mantissa bits each way -- the grade of the forward's bf16x3 GEMMs): 3 - 6e-6 of a level's largest entry measured, against
+    2e-7 for the window kernel twice and 2e-4 for the bf16x3 path's stated bound."""
+    for case in CASES:
+        win = other_process(str(tmp_path), 0, case, False, precision=precision)
+        box = other_process(str(tmp_path), 2, case, False, precision=precision)
+        for k in ("d_vox4", "d_vox5"):
+            assert np.abs(win[k]).max() > 0
+            assert rel_max(box[k], win[k]) < 3e-5, (k, rel_max(box[k], win[k]))
+            assert not np.array_equal(box[k], win[k])                      # the other kernel did run
+        assert rel_max(box["d_vox3"], win["d_vox3"]) < 3e-6                 # (fp32 atomics either way)
+
+
 def test_matrix_core_adjoint_against_the_fp32_grade_backward():
     """... and against the bf16x3 backward (fp32 atomics, fp32-grade dX): the fp16 mode's stated L2 bound (tests/test_hip_backward.py)."""
     got = coarse_level_gradients("one_image", False)
@@ -104,4 +120,4 @@ def test_matrix_core_adjoint_against_the_fp32_grade_backward():
 
 if __name__ == "__main__":
     sys.path.insert(0, ROOT)
-    np.savez(sys.argv[1], **coarse_level_gradients(sys.argv[2], bool(int(sys.argv[3]))))
+    np.savez(sys.argv[1], **coarse_level_gradients(sys.argv[2], bool(int(sys.argv[3])), precision=sys.argv[4]))
