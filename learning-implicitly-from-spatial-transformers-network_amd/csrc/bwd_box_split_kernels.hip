@@ -4,7 +4,7 @@
 // bits per operand, the grade of the forward's bf16x3 products), the box accumulated in fp32 and flushed as float atomics
 // into the level's zeroed gradient -- 256 contiguous bytes per instruction, like k_scatter_vox_win's fp32 flush.
 //   staging: the dX rows of 8 points are loaded as fp32, split, and written as two [sample][128] bf16 images (the fp16
-//            kernel's swizzle); no register prefetch (a chunk's fp32 rows are 28 KB);
+//            kernel's swizzle), the next chunk's fp32 pieces requested a chunk ahead (32 registers);
 //   LDS:     64 KB for the fp32 box (the 2 x 2 staging images share it) + 8.5 KB of tables: two workgroups per CU.
 // Runs, tiles, lane roles and the weights' arithmetic are those of k_scatter_vox_box.
 #include "list_common.h"
@@ -146,7 +146,21 @@ __global__ __launch_bounds__(256, 2) void k_scatter_vox_box_split(ScatterParams 
     // staging of chunk ci: rows (point, slot j < 7) x 16 pieces of 8 channels = 896 pieces, 3.5 per thread: 32 B of fp32
     // in, 16 B of hi and 16 B of lo out (chunk ^ (j & 3) << 2, 8-B halfs swapped for odd points: the fp16 kernel's image)
     const int nchunks = (count + kSplChunkPts - 1) / kSplChunkPts;
-    auto stage_chunk = [&](int ci) {
+    float4 sva[4], svb[4];                                      // the next chunk's fp32 pieces, requested a chunk ahead
+    auto stage_load = [&](int ci) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = tid + 256 * e;
+        const int r = i >> 4, chunk = i & 15;
+        const int pl = r / LIST_N_STENCIL, j = r - pl * LIST_N_STENCIL;
+        sva[e] = make_float4(0.f, 0.f, 0.f, 0.f); svb[e] = sva[e];
+        if (i < L::kStageRows * 16 && ci * kSplChunkPts + pl < count) {
+          const float* src = dx + (row0 + first + ci * kSplChunkPts + pl) * sp.g.Kp + col_off + j * kSplC + chunk * 8;
+          sva[e] = *(const float4*)src; svb[e] = *(const float4*)(src + 4);
+        }
+      }
+    };
+    auto stage_store = [&](int ci) {
       char* buf = smem + L::stage + (ci & 1) * (2 * L::plane_bytes);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -154,23 +168,21 @@ __global__ __launch_bounds__(256, 2) void k_scatter_vox_box_split(ScatterParams 
         if (i >= L::kStageRows * 16) continue;
         const int r = i >> 4, chunk = i & 15;
         const int pl = r / LIST_N_STENCIL, j = r - pl * LIST_N_STENCIL;
-        uint2 h0 = make_uint2(0u, 0u), h1 = h0, l0 = h0, l1 = h0;
-        if (ci * kSplChunkPts + pl < count) {
-          const float* src = dx + (row0 + first + ci * kSplChunkPts + pl) * sp.g.Kp + col_off + j * kSplC + chunk * 8;
-          const float4 a = *(const float4*)src, b = *(const float4*)(src + 4);
-          split4(a, h0, l0);
-          split4(b, h1, l1);
-        }
+        uint2 h0, h1, l0, l1;
+        split4(sva[e], h0, l0);
+        split4(svb[e], h1, l1);
         const int off = r * RB + ((chunk ^ ((j & 3) << 2)) << 4);
         const bool odd = pl & 1;
         *(uint4*)(buf + off) = odd ? make_uint4(h1.x, h1.y, h0.x, h0.y) : make_uint4(h0.x, h0.y, h1.x, h1.y);
         *(uint4*)(buf + L::plane_bytes + off) = odd ? make_uint4(l1.x, l1.y, l0.x, l0.y) : make_uint4(l0.x, l0.y, l1.x, l1.y);
       }
     };
+    stage_load(0);
 #pragma unroll 1
     for (int ci = 0; ci < nchunks; ++ci) {
-      stage_chunk(ci);
+      stage_store(ci);
       __syncthreads();                 // (one barrier per chunk: the other buffer was last read before the previous barrier)
+      if (ci + 1 < nchunks) stage_load(ci + 1);
       const char* buf = smem + L::stage + (ci & 1) * (2 * L::plane_bytes);
 #pragma unroll 1
       for (int ks = 0; ks < kSplChunkPts / 4; ++ks) {
