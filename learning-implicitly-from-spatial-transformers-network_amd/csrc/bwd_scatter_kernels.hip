@@ -1147,8 +1147,11 @@ struct TransPt { int64_t o00; int sx, sy; int row, b, valid; float wx0, wx1, wy0
 // grid = rows/64, block = 256: the first 64 threads project the workgroup's points (pixel order), then
 // the workgroup walks them with lanes over channel octets (16-B loads of the four taps and of dX), a
 // whole number of points per pass; wave shuffles + LDS reduce the two coordinate derivatives per point.
+#ifndef LIST_TRANS_VGPR_ATTR
+#define LIST_TRANS_VGPR_ATTR
+#endif
 template <int F16, int DXH>
-__global__ __launch_bounds__(256) void k_trans_grad(ScatterParams sp, const void* __restrict__ img_map,
+__global__ __launch_bounds__(256) LIST_TRANS_VGPR_ATTR void k_trans_grad(ScatterParams sp, const void* __restrict__ img_map,
                                                     const float* __restrict__ trans_mat, int ms, int Ct,
                                                     float clamp_hi, int img_off, float* __restrict__ grad_T) {
   __shared__ TransPt tp[kGatherRows];

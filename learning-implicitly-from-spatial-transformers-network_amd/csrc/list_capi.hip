@@ -1160,7 +1160,10 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   // resize (it needs only the map gradient), then -- behind dW0's event -- the trans_mat gradient.  In line the stages
   // keep their order (and their stage events their meaning).
   if (!(bwd_knockout() & 32)) {
-    const bool split = forked && ga->grad_trans_mat;
+    // (LIST_BWD_TRANS_UNORDERED=1, diagnostic: the old order -- the stage right behind the map gradient, beside dW0 --
+    // for tools/trans_noise_probe2.py)
+    static const bool unordered = [] { const char* e = getenv("LIST_BWD_TRANS_UNORDERED"); return e && e[0] == '1'; }();
+    const bool split = forked && ga->grad_trans_mat && !unordered;
     LIST_TRY(launch_img_grad(sp, L, *a, bins_pix, nslots, bwp + bw.recs, ga->grad_img_map, map_f16,
                              split ? nullptr : ga->grad_trans_mat, ga->stage_events, s, bwp + bw.img_heavy,
                              bw.img_heavy_bytes), "image gradient launch");
