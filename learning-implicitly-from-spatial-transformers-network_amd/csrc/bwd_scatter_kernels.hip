@@ -1155,7 +1155,7 @@ __global__ __launch_bounds__(256) LIST_TRANS_VGPR_ATTR void k_trans_grad(Scatter
                                                     const float* __restrict__ trans_mat, int ms, int Ct,
                                                     float clamp_hi, int img_off, float* __restrict__ grad_T) {
   __shared__ TransPt tp[kGatherRows];
-  __shared__ float s_gx[kGatherRows][4], s_gy[kGatherRows][4];
+  __shared__ float s_gx[kGatherRows][8], s_gy[kGatherRows][8];     // per point: <= 4 waves x 2 halves of partials
   const int blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t img_stride = (int64_t)ms * ms * Ct;
@@ -1176,7 +1176,7 @@ __global__ __launch_bounds__(256) LIST_TRANS_VGPR_ATTR void k_trans_grad(Scatter
     t.px = p.x; t.py = p.y; t.pz = p.z;
     tp[threadIdx.x] = t;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { s_gx[threadIdx.x][w] = 0.f; s_gy[threadIdx.x][w] = 0.f; }
+    for (int w = 0; w < 8; ++w) { s_gx[threadIdx.x][w] = 0.f; s_gy[threadIdx.x][w] = 0.f; }
   }
   __syncthreads();
   const int lq = Ct / 8;                                   // lanes that cover one point
@@ -1202,12 +1202,20 @@ __global__ __launch_bounds__(256) LIST_TRANS_VGPR_ATTR void k_trans_grad(Scatter
           gy = fmaf(g[e], t.wx0 * (a10 - m00[e]) + t.wx1 * (a11 - a01), gy);
         }
       }
-      // lanes of one point sit in whole waves (lq >= 64) or in aligned sub-wave groups (lq < 64)
-      const int width = lq < 64 ? lq : 64;
-      for (int off = width >> 1; off > 0; off >>= 1) { gx += __shfl_xor(gx, off); gy += __shfl_xor(gy, off); }
-      if ((lane & (width - 1)) == 0) {
-        if (lq >= 64) { s_gx[i + pp][wave % (lq / 64)] = gx; s_gy[i + pp][wave % (lq / 64)] = gy; }
-        else { s_gx[i + pp][0] = gx; s_gy[i + pp][0] = gy; }
+      // lanes of one point sit in whole waves (lq >= 64) or in aligned sub-wave groups (lq < 64).  Whole waves: the two
+      // 32-lane halves keep partials of their own (row-level DPP adds only) -- with the halves combined by __shfl_xor(.,
+      // 32), a ds_bpermute_b32 behind this loop's loads, ONE point's gy came out different in up to 59 of 60 forked calls
+      // whenever the wave shared its CU with the weight-gradient GEMM (ds_read_b64_tr_b16 + LDS-DMA); without that one
+      // instruction pair: 0 of 240 (profiles/r04b_trans_mat_interference.txt)
+      if (lq >= 64) {
+        for (int off = 16; off > 0; off >>= 1) { gx += __shfl_xor(gx, off); gy += __shfl_xor(gy, off); }
+        if ((lane & 31) == 0) {
+          const int slot = 2 * (wave % (lq / 64)) + (lane >> 5);
+          s_gx[i + pp][slot] = gx; s_gy[i + pp][slot] = gy;
+        }
+      } else {
+        for (int off = lq >> 1; off > 0; off >>= 1) { gx += __shfl_xor(gx, off); gy += __shfl_xor(gy, off); }
+        if ((lane & (lq - 1)) == 0) { s_gx[i + pp][0] = gx; s_gy[i + pp][0] = gy; }
       }
     }
   } else {
@@ -1239,8 +1247,10 @@ __global__ __launch_bounds__(256) LIST_TRANS_VGPR_ATTR void k_trans_grad(Scatter
   const TransPt t = tp[threadIdx.x];
   const int b = t.valid ? t.b : -1;
   if (t.valid) {
-    const float gix = (s_gx[threadIdx.x][0] + s_gx[threadIdx.x][1]) + (s_gx[threadIdx.x][2] + s_gx[threadIdx.x][3]);
-    const float giy = (s_gy[threadIdx.x][0] + s_gy[threadIdx.x][1]) + (s_gy[threadIdx.x][2] + s_gy[threadIdx.x][3]);
+    const float* px_ = s_gx[threadIdx.x];
+    const float* py_ = s_gy[threadIdx.x];
+    const float gix = ((px_[0] + px_[1]) + (px_[2] + px_[3])) + ((px_[4] + px_[5]) + (px_[6] + px_[7]));
+    const float giy = ((py_[0] + py_[1]) + (py_[2] + py_[3])) + ((py_[4] + py_[5]) + (py_[6] + py_[7]));
     const float half = (float)(ms - 1) * 0.5f;
     const float inv_s = sp.scale[1];
     // d/d(gx) = half * d/d(ix)  (grid_sampler unnormalize);  d/du = (1/half) * d/d(gx)
