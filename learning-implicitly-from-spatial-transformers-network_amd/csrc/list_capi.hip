@@ -1156,7 +1156,8 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
   // d_trans_mat off by 1e-4 .. 7e-3 of its largest entry in 4 - 59 of 60 calls, depending on what else ran (tools/
   // trans_noise_probe2.py, profiles/r04b_trans_mat_interference.txt: never with dW0 left out, never in line, never once
   // the kernel held more registers or LDS than fit beside dW0; its inputs, its LDS records and every other gradient
-  // were bit-stable).  The cause below the ISA was not found; the order removes the overlap: map gradient, adjoint
+  // were bit-stable).  It was later localised to the one ds_bpermute pair of the kernel's loop, which is gone
+  // (bwd_scatter_kernels.hip); the order stays as a second fence and removes the overlap: map gradient, adjoint
   // resize (it needs only the map gradient), then -- behind dW0's event -- the trans_mat gradient.  In line the stages
   // keep their order (and their stage events their meaning).
   if (!(bwd_knockout() & 32)) {

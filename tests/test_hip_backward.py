@@ -249,7 +249,8 @@ def test_trans_mat_gradient_is_stable_beside_the_weight_gradient(hip):
     """Regression (round 4): in the forked backward k_trans_grad used to run while dW0 did, and whenever one of its waves shared a
     SIMD with the weight-gradient GEMM's one point's v-derivative came out different: d_trans_mat off by 1e-4 .. 7e-3 of its
     largest entry in 7 - 100 % of the calls once other work had moved the allocator, every other gradient bit-stable
-    (list_capi.hip orders the stage behind dW0 now).  The order of the fp32 atomics alone moves d_trans_mat by 3e-7."""
+    (localised to one ds_bpermute pair of the kernel's loop, which is gone; list_capi.hip orders the stage behind dW0 as well).
+    The order of the fp32 atomics alone moves d_trans_mat by 3e-7."""
     c = cases._case(seed=909, batch=4, n=6000, img_res=64, vox_res=32)
     gs = synth.normalish(5, (4, 6000))
     big = cases._case(seed=8181, batch=2, n=1500, img_res=64, vox_res=128)
