@@ -395,8 +395,9 @@ typedef struct ListQueryGradArgs {
                                       /*   order.  [1] carries dW0 and the 16^3 window level, the longest chain: */
                                       /*   create it with hipStreamCreateWithPriority(.., -1) (-0.06 ms per      */
                                       /*   step).  [2] (ABI 9, optional beside the other two): the 8^3 window    */
-                                      /*   level, which otherwise waits behind the gathers on `stream` (same     */
-                                      /*   step with the synthetic camera, -0.2 ms with the points on the clamp) */
+                                      /*   level, which otherwise waits behind the gathers on `stream`, and then */
+                                      /*   the trans_mat gradient (-0.1 ms per step, -0.4 with the points on     */
+                                      /*   the clamp)                                                            */
   const ListMap2D* grad_img_levels;   /* optional: LIST_N_IMG_LEVELS descriptors as list_img_map_grad_to_levels   */
                                       /*   takes them.  The adjoint resize then runs inside this call, beside the */
                                       /*   voxel scatters still in flight on the auxiliary streams (needs         */

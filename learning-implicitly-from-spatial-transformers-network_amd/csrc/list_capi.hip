@@ -1172,9 +1172,13 @@ int list_sdf_query_bwd(const ListQueryGradArgs* ga, void* stream) {
       LIST_TRY(launch_img_grad_to_levels(ga->grad_img_map, a->B, a->map_size, L.img_C, ga->grad_img_levels, s, map_f16,
                                          scale), "img_grad_to_levels launch");
     if (split) {
-      if (ev_dw0) LIST_TRY(hipStreamWaitEvent(s, ev_dw0, 0), "stream order");
+      // ... on aux_streams[2] where there is one (idle once the 8^3 window level is done) instead of at the end of `s`:
+      // training step 6.43 -> 6.36 ms, 6.52 -> 6.32 with the points on the clamp (LIST_BWD_TRANS_WIN2=0: on `s`)
+      static const bool on_win2 = [] { const char* e = getenv("LIST_BWD_TRANS_WIN2"); return !(e && e[0] == '0'); }();
+      const hipStream_t st = (on_win2 && s_win2 != s) ? s_win2 : s;
+      if (ev_dw0) LIST_TRY(hipStreamWaitEvent(st, ev_dw0, 0), "stream order");
       LIST_TRY(launch_img_grad(sp, L, *a, bins_pix, nslots, bwp + bw.recs, nullptr, map_f16, ga->grad_trans_mat,
-                               ga->stage_events, s, nullptr, 0), "trans_mat gradient launch");
+                               ga->stage_events, st, nullptr, 0), "trans_mat gradient launch");
     }
   }
   if (bwd_knockout() & 32) { mark(LIST_BWD_IMG); mark(LIST_BWD_TRANS); }
