@@ -460,6 +460,21 @@ __global__ __launch_bounds__((C >= 128 ? C : 128)) void k_scatter_vox_win(Scatte
 // the (point, stencil) samples are counting-sorted by their base cell, and each voxel sums the samples
 // of the <= 8 cells it is a corner of and is written ONCE with a plain store -- no atomics, no memset.
 // (The direct scatter of that level moves 2.3 GB through the atomic units, 1.8 ms at the chip's rate.)
+// 8 consecutive channels of a map tap / of dX as floats (one or two 16-B loads)
+template <int F16>
+__device__ __forceinline__ void load8(const void* __restrict__ base, int64_t i, float (&f)[8]) {
+  if (F16) {
+    const uint4 r = *(const uint4*)((const unsigned short*)base + i);
+    f[0] = h2f((unsigned short)(r.x & 0xffff)); f[1] = h2f((unsigned short)(r.x >> 16));
+    f[2] = h2f((unsigned short)(r.y & 0xffff)); f[3] = h2f((unsigned short)(r.y >> 16));
+    f[4] = h2f((unsigned short)(r.z & 0xffff)); f[5] = h2f((unsigned short)(r.z >> 16));
+    f[6] = h2f((unsigned short)(r.w & 0xffff)); f[7] = h2f((unsigned short)(r.w >> 16));
+  } else {
+    const float4 a = *(const float4*)((const float*)base + i), b = *(const float4*)((const float*)base + i + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+  }
+}
+
 struct VoxSample { int off; float fx, fy, fz; };   // dX element offset of the sample's channel 0; w1 per axis
 constexpr int kScanPerBlock = 4096;
 
@@ -610,6 +625,62 @@ __global__ __launch_bounds__(256) void k_vs_gather(ScatterParams sp, ListVoxLeve
   ((float*)gv.data)[vox * C + c] = acc * sp.scale[1];
 }
 
+// The same sums with a lane per (voxel, 8 channels) instead of per (voxel, channel): a sample costs the wave one 16-B
+// record load and one 16-B (fp16 dX) load per EIGHT voxel-samples instead of one of each per voxel-sample -- the kernel
+// above is bound by the number of vector-memory instructions (a 2-B load per lane is a whole instruction), not by bytes.
+// Every channel still adds its samples in the same order with the same weights: bit-identical results.
+// Lanes of a wave belong to 64 / (C / 8) voxels with different sample counts: they idle in the longer lists' tails.
+template <int C, int DXH>
+__global__ __launch_bounds__(256) void k_vs_gather8(ScatterParams sp, ListVoxLevel gv, const int* __restrict__ ends,
+                                                    const VoxSample* __restrict__ recs, int64_t n_vox) {
+  constexpr int TPV = C / 8, VPB = 256 / TPV, NB = 4;
+  const int64_t vox = (int64_t)blockIdx.x * VPB + threadIdx.x / TPV;
+  const int c8 = (threadIdx.x % TPV) * 8;
+  if (vox >= n_vox) return;
+  const int W = gv.W, H = gv.H, D = gv.D;
+  const int x = (int)(vox % W), y = (int)((vox / W) % H), z = (int)((vox / ((int64_t)W * H)) % D);
+  const int b = (int)(vox / ((int64_t)W * H * D));
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  int r_lo[4], r_mid[4], r_hi[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int yy = y - (q & 1), zz = z - (q >> 1);
+    r_lo[q] = r_mid[q] = r_hi[q] = 0;
+    if (yy < 0 || zz < 0) continue;
+    const int bin1 = ((b * D + zz) * H + yy) * W + x;          // cell x (corner dx = 0)
+    r_mid[q] = bin1 > 0 ? ends[bin1 - 1] : 0;                  // = end of cell x-1
+    r_lo[q] = x > 0 ? (bin1 > 1 ? ends[bin1 - 2] : 0) : r_mid[q];
+    r_hi[q] = ends[bin1];
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int dy = q & 1, dz = q >> 1;
+    const int s_lo = r_lo[q], s_mid = r_mid[q], s_hi = r_hi[q];
+    for (int s = s_lo; s < s_hi; s += NB) {
+      VoxSample r[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) r[u] = recs[min(s + u, s_hi - 1)];
+      float g[NB][8];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) load8<DXH>(sp.dx, (int64_t)r[u].off + c8, g[u]);
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const bool dx = (s + u) < s_mid;                     // the sample lies in cell x-1: corner +1 in x
+        float w = (dx ? r[u].fx : 1.f - r[u].fx) * (dy ? r[u].fy : 1.f - r[u].fy) * (dz ? r[u].fz : 1.f - r[u].fz);
+        if (s + u >= s_hi) w = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(w, g[u][e], acc[e]);
+      }
+    }
+  }
+  const float inv_s = sp.scale[1];
+  float* out = (float*)gv.data + vox * C + c8;
+  *(float4*)out = make_float4(acc[0] * inv_s, acc[1] * inv_s, acc[2] * inv_s, acc[3] * inv_s);
+  *(float4*)(out + 4) = make_float4(acc[4] * inv_s, acc[5] * inv_s, acc[6] * inv_s, acc[7] * inv_s);
+}
+
 template <int C>
 static hipError_t gather_level(const ScatterParams& sp, const ListVoxLevel& gv, int col_off, int B,
                                const VoxGatherBuffers& vb, hipStream_t s) {
@@ -623,6 +694,16 @@ static hipError_t gather_level(const ScatterParams& sp, const ListVoxLevel& gv, 
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, s, vb.sums, nb);
   hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(kScanThreads), 0, s, vb.bins, (int)n_vox, vb.sums);
   hipLaunchKernelGGL(k_vs_scatter<C>, gs, dim3(256), 0, s, sp, gv, vb.keys, vb.bins, (VoxSample*)vb.recs, col_off);
+  static const bool octets = [] { const char* e = getenv("LIST_VS_GATHER8"); return !(e && e[0] == '0'); }();
+  if (octets && (col_off % 8) == 0 && (sp.g.Kp % 8) == 0 && (reinterpret_cast<uintptr_t>(gv.data) & 15) == 0) {
+    constexpr int VPB8 = 256 / (C / 8);
+    const dim3 g8((unsigned)((n_vox + VPB8 - 1) / VPB8));
+    if (sp.dx_f16)
+      hipLaunchKernelGGL((k_vs_gather8<C, 1>), g8, dim3(256), 0, s, sp, gv, vb.bins, (const VoxSample*)vb.recs, n_vox);
+    else
+      hipLaunchKernelGGL((k_vs_gather8<C, 0>), g8, dim3(256), 0, s, sp, gv, vb.bins, (const VoxSample*)vb.recs, n_vox);
+    return hipGetLastError();
+  }
   const dim3 gg((unsigned)((n_vox + 256 / C - 1) / (256 / C)));
   if (sp.dx_f16)
     hipLaunchKernelGGL((k_vs_gather<C, 1>), gg, dim3(256), 0, s, sp, gv, vb.bins, (const VoxSample*)vb.recs, n_vox);
@@ -1124,21 +1205,6 @@ __global__ __launch_bounds__(256) void k_img_grad_atomic(ScatterParams sp, const
 template <int F16>
 __device__ __forceinline__ float map_at(const void* __restrict__ m, int64_t i) {
   return F16 ? h2f(((const unsigned short*)m)[i]) : ((const float*)m)[i];
-}
-
-// 8 consecutive channels of a map tap / of dX as floats (one or two 16-B loads)
-template <int F16>
-__device__ __forceinline__ void load8(const void* __restrict__ base, int64_t i, float (&f)[8]) {
-  if (F16) {
-    const uint4 r = *(const uint4*)((const unsigned short*)base + i);
-    f[0] = h2f((unsigned short)(r.x & 0xffff)); f[1] = h2f((unsigned short)(r.x >> 16));
-    f[2] = h2f((unsigned short)(r.y & 0xffff)); f[3] = h2f((unsigned short)(r.y >> 16));
-    f[4] = h2f((unsigned short)(r.z & 0xffff)); f[5] = h2f((unsigned short)(r.z >> 16));
-    f[6] = h2f((unsigned short)(r.w & 0xffff)); f[7] = h2f((unsigned short)(r.w >> 16));
-  } else {
-    const float4 a = *(const float4*)((const float*)base + i), b = *(const float4*)((const float*)base + i + 4);
-    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
-  }
 }
 
 struct TransPt { int64_t o00; int sx, sy; int row, b, valid; float wx0, wx1, wy0, wy1; float X, Y, den; int pass_u, pass_v;
